@@ -1,0 +1,133 @@
+/*
+ * wdpm.h — C ABI of the MI355X-native WDPM water-redistribution ("smoothing") path.
+ *
+ * This is the drop-in boundary for the hot path of CentreForHydrology/WDPM's WDPMCL:
+ * the 9-colour 3x3 water-transfer sweep and its max-change convergence test.  The
+ * reference has no library API for this path: its seam is three C
+ * functions on globals plus the OpenCL kernel argument lists.  Every entry point below
+ * cites the reference interface it replaces (file:line into the reference tree's
+ * src/WDPMCL.c and src/runoff.cl).
+ *
+ * Conventions
+ *   - plain C types only; every function returns 0 on success, non-zero on failure, and
+ *     wdpm_last_error() then returns a message.  Nothing throws across this boundary.
+ *   - rasters are PADDED, ROW-MAJOR double arrays: (nrows+2) x (ncols+2); interior cell
+ *     (i,j) of the ArcASCII file is element [(i+1)*(ncols+2) + (j+1)]  (ref "bigdem",
+ *     "bigwater", WDPMCL.c:796-807).  The reference OpenCL path is column-major
+ *     (WDPMCL.c:1129-1134); this ABI is not.
+ *   - the host owns host memory; the library owns device memory for the context's life.
+ *   - a context may hold a SLAB (contiguous block of padded rows) of a larger raster for
+ *     row-block domain decomposition across GPUs; slab_row0 must be a multiple of 3 so the
+ *     colour alignment of the passes is the same on every slab.
+ *
+ * Two libraries export this same ABI:
+ *   wdpm_amd/csrc  -> libwdpm_hip.so   the product (HIP kernels for gfx950; no CPU fallback)
+ *   oracle/        -> libwdpm_oracle.so the CPU restatement used ONLY by tests/bench baseline
+ */
+#ifndef WDPM_H
+#define WDPM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WDPM_ABI_VERSION 1
+
+/* module selector: argv[1] of WDPMCL ("add" | "subtract" | "drain"), WDPMCL.c:308-355 */
+enum { WDPM_ADD = 0, WDPM_SUBTRACT = 1, WDPM_DRAIN = 2 };
+
+/* which stencil kernel implementation wdpm_iterate uses (product library only).
+ * AUTO picks FUSED.  PASS = one launch per colour pass (9 per iteration), the direct
+ * analogue of the reference's 9 clEnqueueNDRangeKernel calls (WDPMCL.c:1184-1206);
+ * FUSED = one launch per iteration, register-resident marching window. */
+enum { WDPM_KERNEL_AUTO = 0, WDPM_KERNEL_PASS = 1, WDPM_KERNEL_FUSED = 2 };
+
+typedef struct wdpm_ctx wdpm_ctx; /* opaque */
+
+typedef struct wdpm_params {
+  int32_t module;       /* WDPM_ADD | WDPM_SUBTRACT | WDPM_DRAIN */
+  int32_t nrows;        /* NROWS of the whole raster (file rows R), WDPMCL.c:553 */
+  int32_t ncols;        /* NCOLS of the whole raster (file cols C), WDPMCL.c:552 */
+  int32_t drainrow;     /* drain cell, padded coords of the WHOLE raster (WDPMCL.c:1005-1017); drain only */
+  int32_t draincol;
+  int32_t slab_row0;    /* first padded row of the whole raster held by this context (multiple of 3) */
+  int32_t slab_rows;    /* padded rows held (0 => all nrows+2 rows, slab_row0 must then be 0) */
+  int32_t device;       /* HIP device ordinal (replaces create_device(), WDPMCL.c:80-121) */
+  int32_t kernel;       /* WDPM_KERNEL_* */
+  int32_t reserved;
+  double  missingvalue; /* NODATA_VALUE, WDPMCL.c:554 */
+} wdpm_params;
+
+/* -- lifetime ------------------------------------------------------------------------------
+ * replaces OpenCL context/program/queue/kernel creation (WDPMCL.c:598-638) and the per-block
+ * clCreateBuffer/clReleaseMemObject churn (WDPMCL.c:1138-1141,1223-1227): buffers persist. */
+int  wdpm_create(wdpm_ctx **out, const wdpm_params *p);
+void wdpm_destroy(wdpm_ctx *ctx);                      /* WDPMCL.c:1475-1483 */
+const char *wdpm_last_error(void);                     /* replaces exitOnFail(), WDPMCL.c:225-232 */
+const char *wdpm_backend_name(void);                   /* "hip-gfx950" or "oracle-cpu" */
+int  wdpm_abi_version(void);
+
+/* -- data movement --------------------------------------------------------------------------
+ * upload: replaces the two blocking clEnqueueWriteBuffer calls (WDPMCL.c:1143-1153).
+ * Arrays hold slab_rows x (ncols+2) doubles (the context's slab only). */
+int wdpm_upload(wdpm_ctx *ctx, const double *bigdem, const double *bigwater);
+int wdpm_upload_water(wdpm_ctx *ctx, const double *bigwater);
+/* download: replaces clEnqueueReadBuffer of bigwater (WDPMCL.c:1217-1221) */
+int wdpm_download_water(wdpm_ctx *ctx, double *bigwater);
+/* copy `nrows` slab rows starting at slab-local row `row` to/from host (halo refresh, tests) */
+int wdpm_download_rows(wdpm_ctx *ctx, int32_t row, int32_t nrows, double *dst);
+int wdpm_upload_rows(wdpm_ctx *ctx, int32_t row, int32_t nrows, const double *src);
+
+/* totaldrain: the reference global (WDPMCL.c:236,1029), device-resident here (replaces
+ * d_totaldrain, WDPMCL.c:1168-1178,1208-1213). */
+int wdpm_set_totaldrain(wdpm_ctx *ctx, double v);
+int wdpm_get_totaldrain(wdpm_ctx *ctx, double *v);
+
+/* -- the block loop, step by step (WDPMCL.c:1049-1377 minus printing/termination) ------------
+ * begin_block: threshold flush over the whole padded slab, border included (WDPMCL.c:1055-1065),
+ *              olddrain = totaldrain (:1066-1068), snapshot oldwater = bigwater (:1069-1073). */
+int wdpm_begin_block(wdpm_ctx *ctx, double thres);
+/* iterate: n_iter iterations, each = 9 colour passes in the order oi=1..3 outer, oj=1..3 inner
+ *          (WDPMCL.c:1094-1106; kernels add/subtract runoff.cl:137-164), stencil runoffs()
+ *          (WDPMCL.c:1934-1964) for add and subtract; for drain runoffd() (:1967-2006) with the
+ *          drain-centre gate (:1081-1082) and drain() (:1859-1897) after each iteration (:1089). */
+int wdpm_iterate(wdpm_ctx *ctx, int32_t n_iter);
+/* one colour pass (oi,oj in 1..3) — the unit the reference launches (WDPMCL.c:1187-1204);
+ * exposed for golden-vector tests of single passes. */
+int wdpm_pass(wdpm_ctx *ctx, int32_t oi, int32_t oj);
+/* drain() alone (WDPMCL.c:1859-1897): totaldrain += sum over outlet 3x3; zero the 9 cells */
+int wdpm_drain_outlet(wdpm_ctx *ctx);
+/* max_diff over slab-local rows [row_lo,row_hi) of |bigwater-oldwater| where bigdem>missing,
+ * seeded with diff[0][0] of the slab's first row when row_lo==0 (WDPMCL.c:1239-1254).
+ * row_lo=0,row_hi=slab_rows gives the reference value for a whole-raster context. */
+int wdpm_max_diff(wdpm_ctx *ctx, int32_t row_lo, int32_t row_hi, double *out);
+/* drain bookkeeping (WDPMCL.c:1257-1268): diffdrain = |totaldrain-olddrain| (NOT yet times
+ * cellarea); final_sum = sum of bigwater over bigdem>missing in row-major order (NOT yet times
+ * cellarea), bit-identical to the reference's sequential summation. */
+int wdpm_drain_stats(wdpm_ctx *ctx, double *diffdrain, double *final_sum);
+/* convenience: begin_block + iterate(n_iter) + max_diff over the whole slab */
+int wdpm_run_block(wdpm_ctx *ctx, int32_t n_iter, double thres, double *max_diff);
+
+/* -- plumbing for multi-GPU drivers (product library; the oracle returns host pointers) ------ */
+/* device pointer of the CURRENT water raster (changes after every wdpm_iterate/wdpm_pass) */
+int wdpm_water_ptr(wdpm_ctx *ctx, void **ptr);
+int wdpm_dem_ptr(wdpm_ctx *ctx, void **ptr);
+/* run all work of this context on the caller's hipStream_t (e.g. torch's current stream) */
+int wdpm_set_stream(wdpm_ctx *ctx, void *hip_stream);
+int wdpm_synchronize(wdpm_ctx *ctx);
+/* device-side timing of the stencil launches since the last reset (HIP events on the
+ * context's stream): number of stencil launches and their summed duration in ms. */
+int wdpm_timing_reset(wdpm_ctx *ctx);
+int wdpm_timing_get(wdpm_ctx *ctx, int64_t *launches, double *ms);
+
+/* -- synthetic DEM generator: integer-seeded, identical on every
+ * host.  Writes an n x n UNPADDED row-major raster. */
+int wdpm_synth_dem(int32_t n, uint64_t seed, double *dem);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WDPM_H */

@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory from the UNMODIFIED reference.
+
+Runs only where /root/reference exists (the build container).  It drives
+oracle/_ref/libwdpm_ref.so (reference src/WDPMCL.c compiled as-is by oracle/Makefile, serial
+functions runoffs/runoffd/drain on the reference's own globals) and oracle/_ref/WDPMCL_ref (the
+reference executable, serial path cpu=0), and writes DATA only:
+
+  stencil_cases.npz   small synthetic rasters: inputs + full-precision water after each of the 9
+                      colour passes of the first iteration and after 1/10/100(/1000) iterations
+  basin5.asc.gz       the reference's sample DEM (dem/basin5.asc), a data file
+  basin5_state.npz    full-precision basin5 states (sha256 + sampled rows) after 1000/3000
+                      iterations of add 100 mm / add 300 mm, and drain after 1000 iterations
+  basin5_cli.json     WDPMCL_ref report lines (iterations, max diff, volumes) and sha256 of the
+                      output rasters for the validation trio (validation/validate_WDPM.sh) and
+                      for BASELINE configs 1-2
+
+    python tests/golden/make_golden.py
+"""
+import ctypes as C
+import gzip
+import hashlib
+import json
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libwdpm_ref.so")
+REF_EXE = os.path.join(ROOT, "oracle", "_ref", "WDPMCL_ref")
+BASIN5 = "/root/reference/dem/basin5.asc"
+
+ADD, SUBTRACT, DRAIN = 0, 1, 2
+
+
+def load_ref():
+    ref = C.CDLL(REF_SO)
+    ref.ref_setup.argtypes = [C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_int]
+    ref.ref_pass.argtypes = [C.c_int, C.c_int, C.c_int]
+    ref.ref_iterate.argtypes = [C.c_int, C.c_int]
+    ref.ref_get_water.argtypes = [C.c_void_p]
+    ref.ref_get_totaldrain.restype = C.c_double
+    return ref
+
+
+def pad(dem, water, missing):
+    R, Cc = dem.shape
+    bd = np.full((R + 2, Cc + 2), missing, dtype=np.float64)
+    bw = np.zeros((R + 2, Cc + 2), dtype=np.float64)
+    bd[1:-1, 1:-1] = dem
+    bw[1:-1, 1:-1] = water
+    return bd, bw
+
+
+def find_drain(bd):
+    """WDPMCL.c:1005-1017: first (row-major, strict <) minimum among bigdem > 0."""
+    best, pos = 100000000.0, (0, 0)
+    R, Cc = bd.shape
+    for i in range(R):
+        for j in range(Cc):
+            v = bd[i, j]
+            if v > 0 and v < best:
+                best, pos = v, (i, j)
+    return pos
+
+
+def ref_water(ref, shape):
+    out = np.empty(shape, dtype=np.float64)
+    ref.ref_get_water(out.ctypes.data)
+    return out
+
+
+def synth_case(rng, R, Cc, missing_frac, dry_frac, depth):
+    missing = -99999.0
+    y, x = np.mgrid[0:R, 0:Cc]
+    dem = 500.0 + 2.0 * np.sin(x / 3.1) * np.cos(y / 2.3) + rng.normal(0, 0.4, (R, Cc)) - 0.01 * (x + y)
+    dem = np.round(dem, 4)
+    dem[rng.random((R, Cc)) < missing_frac] = missing
+    water = np.where(rng.random((R, Cc)) < dry_frac, 0.0, depth * rng.random((R, Cc)))
+    water = np.where(dem > missing, water, 0.0)
+    return dem, water, missing
+
+
+def make_stencil_cases(ref):
+    rng = np.random.default_rng(20261003)
+    out = {}
+    index = []
+    shapes = [(1, 1, 0.0, 0.0), (2, 5, 0.0, 0.2), (3, 3, 0.0, 0.0), (7, 9, 0.1, 0.3), (20, 17, 0.05, 0.3),
+              (33, 31, 0.08, 0.5), (64, 50, 0.05, 0.2), (48, 200, 0.03, 0.1), (95, 130, 0.5, 0.6)]
+    for ci, (R, Cc, mf, df) in enumerate(shapes):
+        dem, water, missing = synth_case(rng, R, Cc, mf, df, 0.3)
+        bd, bw = pad(dem, water, missing)
+        for module in (ADD, DRAIN):
+            name = f"c{ci}_m{module}"
+            dr, dc = (0, 0)
+            td0 = 0.0
+            if module == DRAIN:
+                if not (bd > 0).any():
+                    continue
+                dr, dc = find_drain(bd)
+                td0 = max(bw[dr, dc], 0.0)
+            out[name + "_dem"] = bd
+            out[name + "_w0"] = bw
+            meta = dict(name=name, R=R, C=Cc, module=module, missing=missing, drainrow=int(dr), draincol=int(dc),
+                        td0=td0, stages=[])
+            # nine single passes of the first iteration
+            ref.ref_setup(R, Cc, missing, bd.ctypes.data, bw.ctypes.data, td0, dr, dc)
+            k = 0
+            for oi in ((1, 2, 3) if R * Cc <= 64 * 50 else ()):  # single passes only for the small cases
+                for oj in (1, 2, 3):
+                    ref.ref_pass(module, oi, oj)
+                    k += 1
+                    out[f"{name}_p{k}"] = ref_water(ref, bd.shape)
+                    meta.setdefault("td_pass", []).append(ref.ref_get_totaldrain())
+            # 1, 10, 100 (1000 for small) iterations from the initial state
+            iters = [1, 10, 100] + ([1000] if R * Cc <= 64 * 50 else [])
+            ref.ref_setup(R, Cc, missing, bd.ctypes.data, bw.ctypes.data, td0, dr, dc)
+            done = 0
+            for n in iters:
+                ref.ref_iterate(module, n - done)
+                done = n
+                out[f"{name}_i{n}"] = ref_water(ref, bd.shape)
+                meta["stages"].append(dict(iters=n, totaldrain=ref.ref_get_totaldrain()))
+            index.append(meta)
+    out["index_json"] = np.frombuffer(json.dumps(index).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, "stencil_cases.npz"), **out)
+    print("stencil_cases.npz:", len(index), "cases")
+
+
+def read_asc(path):
+    with open(path) as f:
+        hdr = [f.readline().split() for _ in range(6)]
+        vals = np.array(f.read().split(), dtype=np.float64)
+    ncols, nrows = int(float(hdr[0][1])), int(float(hdr[1][1]))
+    return vals.reshape(nrows, ncols), {h[0]: float(h[1]) for h in hdr}
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def make_basin5_state(ref):
+    dem, hdr = read_asc(BASIN5)
+    missing = hdr["NODATA_VALUE"]
+    R, Cc = dem.shape
+    out, index = {}, []
+    for module, add_mm, iters in ((ADD, 100.0, (1000, 3000)), (ADD, 300.0, (1000, 3000))):
+        water = np.where(dem > missing, add_mm / 1000.0, 0.0)  # NULL water file, rof 1.0 (WDPMCL.c:779-792)
+        bd, bw = pad(dem, water, missing)
+        thres = 0.005 / 1000
+        ref.ref_setup(R, Cc, missing, bd.ctypes.data, bw.ctypes.data, 0.0, 0, 0)
+        done = 0
+        for n in iters:
+            while done < n:
+                # block structure of WDPMCL.c:1055-1125: flush then 1000 iterations
+                w = ref_water(ref, bd.shape)
+                w[w < thres] = 0
+                ref.ref_setup(R, Cc, missing, bd.ctypes.data, w.ctypes.data, 0.0, 0, 0)
+                ref.ref_iterate(module, 1000)
+                done += 1000
+            w = ref_water(ref, bd.shape)
+            name = f"add{int(add_mm)}_k{n}"
+            out[name + "_rows"] = w[::7].copy()
+            index.append(dict(name=name, add_mm=add_mm, iters=n, thres=thres, sha256=sha(w),
+                              sum=float(w[bd > missing].sum()), max=float(w.max())))
+            print(name, index[-1]["sha256"][:16])
+    out["index_json"] = np.frombuffer(json.dumps(index).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, "basin5_state.npz"), **out)
+
+
+def run_cli(args, cwd):
+    p = subprocess.run([REF_EXE] + [str(a) for a in args], cwd=cwd, capture_output=True, text=True)
+    return p.returncode, p.stdout
+
+
+BLOCK_RE = re.compile(r"^\s+(\d+)\s+(-?\d+\.\d+)(?:\s+(-?\d+\.\d+)\s+(-?\d+\.\d+))?\s+(\d+\.\d+)\s*$")
+
+
+def parse_report(text):
+    blocks, summary = [], {}
+    for ln in text.splitlines():
+        m = BLOCK_RE.match(ln)
+        if m and "." in ln:
+            g = m.groups()
+            blocks.append([int(g[0]), g[1]] + ([g[2], g[3]] if g[2] is not None else []))
+        m2 = re.match(r"^\s*(Initial volume|Final volume|Volume change|Volume drained|Final water coverage|"
+                      r"Mean water depth|Depth drained|Max water depth|Drain column:|Drain row:|"
+                      r"Min DEM elevation:|Basin area:|Initial volume:)\s+(-?[\d.]+)", ln)
+        if m2:
+            summary.setdefault(m2.group(1), m2.group(2))
+    return blocks, summary
+
+
+def file_sha(path):
+    with open(path, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
+def make_basin5_cli():
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        dem = os.path.join(td, "basin5.asc")
+        shutil.copy(BASIN5, dem)
+
+        def record(key, args, outfile):
+            rc, text = run_cli(args, td)
+            blocks, summary = parse_report(text)
+            res[key] = dict(args=[str(a) for a in args], rc=rc, blocks=blocks, summary=summary,
+                            out_sha256=file_sha(os.path.join(td, outfile)),
+                            report_sha256_nontiming=hashlib.sha256(strip_timing(text).encode()).hexdigest())
+            print(key, rc, len(blocks), "blocks", summary.get("Final volume"))
+
+        # the validation trio, validation/validate_WDPM.sh:77,88,99 with run_type=0 (serial)
+        record("val_add10", ["add", "basin5.asc", "NULL", "a10.asc", "NULL", 10, 1.0, 1.0, 0, 0, 0.005, 0], "a10.asc")
+        record("val_drain", ["drain", "basin5.asc", "a10.asc", "a10d.asc", "NULL", 0.1, 1.0, 0, 0, 0.005, 0], "a10d.asc")
+        record("val_sub10", ["subtract", "basin5.asc", "a10d.asc", "a10s.asc", "NULL", 10, 1.0, 0, 0, 0.005, 0], "a10s.asc")
+        # BASELINE config 1 (limit 3000) and config 2 (add 300 mm, limit 1000)
+        record("cfg1_add100_k3000", ["add", "basin5.asc", "NULL", "a100.asc", "NULL", 100, 1.0, 1.0, 0, 0, 0.005, 3000], "a100.asc")
+        record("cfg2_add300_k1000", ["add", "basin5.asc", "NULL", "a300.asc", "NULL", 300, 1.0, 1.0, 0, 0, 0.005, 1000], "a300.asc")
+        # scratch/resume + water-file path: add 20 mm on top of a10.asc with a scratch file, limit 2000
+        record("add20_on_a10_scratch", ["add", "basin5.asc", "a10.asc", "a30.asc", "scr.asc", 20, 0.5, 1.0, 0, 0, 0.005, 2000], "a30.asc")
+        res["add20_on_a10_scratch"]["scratch_sha256"] = file_sha(os.path.join(td, "scr.asc"))
+        # keep the 2x3 pothole patch the validation awk scripts sum (lines 268-269, fields 59-61)
+        for key, fn in (("val_add10", "a10.asc"), ("val_drain", "a10d.asc"), ("val_sub10", "a10s.asc")):
+            w, _ = read_asc(os.path.join(td, fn))
+            res[key]["patch_sum"] = float(w[268 - 7:270 - 7, 58:61].sum())
+        # usage / error exits
+        for key, args in (("usage_none", []), ("usage_add", ["add"]), ("usage_badargc", ["add", "x", "y"])):
+            rc, text = run_cli(args, td)
+            res[key] = dict(args=args, rc=rc, stdout=text)
+    with open(os.path.join(HERE, "basin5_cli.json"), "w") as f:
+        json.dump(res, f, indent=1)
+
+
+def strip_timing(text):
+    """Report text with the run-time column / Run Time line removed (they are wall-clock)."""
+    out = []
+    for ln in text.splitlines():
+        m = BLOCK_RE.match(ln)
+        if m:
+            ln = ln[:ln.rstrip().rfind(" ")].rstrip()
+        if ln.strip().startswith("Run Time"):
+            continue
+        out.append(ln.rstrip())
+    return "\n".join(out)
+
+
+def main():
+    if not os.path.exists(REF_SO):
+        sys.exit("build oracle/_ref first: make -C oracle ref")
+    ref = load_ref()
+    make_stencil_cases(ref)
+    with open(BASIN5, "rb") as f, gzip.GzipFile(os.path.join(HERE, "basin5.asc.gz"), "wb", mtime=0) as g:
+        g.write(f.read())
+    make_basin5_state(ref)
+    make_basin5_cli()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,264 @@
+"""ctypes binding of the C ABI declared in include/wdpm.h.
+
+The same binding serves any shared library exporting that ABI.  The product library is
+``wdpm_amd/csrc/libwdpm_hip.so`` (HIP kernels for gfx950); :func:`load_hip` loads it and fails
+loudly when it is missing — there is no CPU fallback in this package.  Tests load the CPU
+oracle through :func:`load` with an explicit path; the package itself never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+ADD, SUBTRACT, DRAIN = 0, 1, 2
+MODULES = {"add": ADD, "subtract": SUBTRACT, "drain": DRAIN}
+KERNEL_AUTO, KERNEL_PASS, KERNEL_FUSED = 0, 1, 2
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB_PATH = os.path.join(_HERE, "csrc", "libwdpm_hip.so")
+
+
+class Params(C.Structure):
+    """struct wdpm_params (include/wdpm.h)."""
+    _fields_ = [
+        ("module", C.c_int32), ("nrows", C.c_int32), ("ncols", C.c_int32),
+        ("drainrow", C.c_int32), ("draincol", C.c_int32),
+        ("slab_row0", C.c_int32), ("slab_rows", C.c_int32),
+        ("device", C.c_int32), ("kernel", C.c_int32), ("reserved", C.c_int32),
+        ("missingvalue", C.c_double),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/wdpm.h declares
+_dp = C.POINTER(C.c_double)
+_vp = C.c_void_p
+SYMBOLS = {
+    "wdpm_create": (C.c_int, [C.POINTER(_vp), C.POINTER(Params)]),
+    "wdpm_destroy": (None, [_vp]),
+    "wdpm_last_error": (C.c_char_p, []),
+    "wdpm_backend_name": (C.c_char_p, []),
+    "wdpm_abi_version": (C.c_int, []),
+    "wdpm_upload": (C.c_int, [_vp, _vp, _vp]),
+    "wdpm_upload_water": (C.c_int, [_vp, _vp]),
+    "wdpm_download_water": (C.c_int, [_vp, _vp]),
+    "wdpm_download_rows": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp]),
+    "wdpm_upload_rows": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp]),
+    "wdpm_set_totaldrain": (C.c_int, [_vp, C.c_double]),
+    "wdpm_get_totaldrain": (C.c_int, [_vp, _dp]),
+    "wdpm_begin_block": (C.c_int, [_vp, C.c_double]),
+    "wdpm_iterate": (C.c_int, [_vp, C.c_int32]),
+    "wdpm_pass": (C.c_int, [_vp, C.c_int32, C.c_int32]),
+    "wdpm_drain_outlet": (C.c_int, [_vp]),
+    "wdpm_max_diff": (C.c_int, [_vp, C.c_int32, C.c_int32, _dp]),
+    "wdpm_drain_stats": (C.c_int, [_vp, _dp, _dp]),
+    "wdpm_run_block": (C.c_int, [_vp, C.c_int32, C.c_double, _dp]),
+    "wdpm_water_ptr": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "wdpm_dem_ptr": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "wdpm_set_stream": (C.c_int, [_vp, _vp]),
+    "wdpm_synchronize": (C.c_int, [_vp]),
+    "wdpm_timing_reset": (C.c_int, [_vp]),
+    "wdpm_timing_get": (C.c_int, [_vp, C.POINTER(C.c_int64), _dp]),
+    "wdpm_synth_dem": (C.c_int, [C.c_int32, C.c_uint64, _vp]),
+}
+
+
+class WdpmError(RuntimeError):
+    pass
+
+
+class Lib:
+    """A loaded shared library exporting the wdpm C ABI."""
+
+    def __init__(self, path: str):
+        if not os.path.exists(path):
+            raise WdpmError(f"wdpm library not found: {path}")
+        self.path = path
+        self.dll = C.CDLL(path)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(self.dll, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        if self.dll.wdpm_abi_version() != 1:
+            raise WdpmError("wdpm ABI version mismatch")
+
+    @property
+    def backend(self) -> str:
+        return self.dll.wdpm_backend_name().decode()
+
+    def check(self, rc: int):
+        if rc != 0:
+            raise WdpmError(self.dll.wdpm_last_error().decode() or f"wdpm error {rc}")
+
+    def synth_dem(self, n: int, seed: int) -> np.ndarray:
+        out = np.empty((n, n), dtype=np.float64)
+        self.check(self.dll.wdpm_synth_dem(n, seed, out.ctypes.data))
+        return out
+
+    def context(self, **kw) -> "Context":
+        return Context(self, **kw)
+
+
+@dataclass
+class _Slab:
+    row0: int
+    rows: int
+
+
+class Context:
+    """One raster (or one row slab of a raster) resident on one device — wraps wdpm_ctx."""
+
+    def __init__(self, lib: Lib, module, nrows: int, ncols: int, missingvalue: float,
+                 drainrow: int = 0, draincol: int = 0, slab_row0: int = 0, slab_rows: int = 0,
+                 device: int = 0, kernel: int = KERNEL_AUTO):
+        self.lib = lib
+        if isinstance(module, str):
+            module = MODULES[module]
+        self.module = module
+        self.nrows, self.ncols = nrows, ncols
+        self.ncp = ncols + 2
+        self.slab = _Slab(slab_row0, slab_rows if slab_rows > 0 else nrows + 2)
+        p = Params(module=module, nrows=nrows, ncols=ncols, drainrow=drainrow, draincol=draincol,
+                   slab_row0=slab_row0, slab_rows=slab_rows, device=device, kernel=kernel,
+                   reserved=0, missingvalue=missingvalue)
+        h = C.c_void_p()
+        lib.check(lib.dll.wdpm_create(C.byref(h), C.byref(p)))
+        self._h = h
+
+    # -- lifetime
+    def close(self):
+        if self._h:
+            self.lib.dll.wdpm_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def shape(self):
+        return (self.slab.rows, self.ncp)
+
+    @staticmethod
+    def _arr(a, shape):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        if a.shape != tuple(shape):
+            raise ValueError(f"expected array of shape {tuple(shape)}, got {a.shape}")
+        return a
+
+    # -- data movement
+    def upload(self, bigdem, bigwater):
+        d, w = self._arr(bigdem, self.shape), self._arr(bigwater, self.shape)
+        self.lib.check(self.lib.dll.wdpm_upload(self._h, d.ctypes.data, w.ctypes.data))
+
+    def upload_water(self, bigwater):
+        w = self._arr(bigwater, self.shape)
+        self.lib.check(self.lib.dll.wdpm_upload_water(self._h, w.ctypes.data))
+
+    def download_water(self) -> np.ndarray:
+        out = np.empty(self.shape, dtype=np.float64)
+        self.lib.check(self.lib.dll.wdpm_download_water(self._h, out.ctypes.data))
+        return out
+
+    def download_rows(self, row: int, nrows: int) -> np.ndarray:
+        out = np.empty((nrows, self.ncp), dtype=np.float64)
+        self.lib.check(self.lib.dll.wdpm_download_rows(self._h, row, nrows, out.ctypes.data))
+        return out
+
+    def upload_rows(self, row: int, src):
+        src = np.ascontiguousarray(src, dtype=np.float64)
+        assert src.ndim == 2 and src.shape[1] == self.ncp
+        self.lib.check(self.lib.dll.wdpm_upload_rows(self._h, row, src.shape[0], src.ctypes.data))
+
+    @property
+    def totaldrain(self) -> float:
+        v = C.c_double()
+        self.lib.check(self.lib.dll.wdpm_get_totaldrain(self._h, C.byref(v)))
+        return v.value
+
+    @totaldrain.setter
+    def totaldrain(self, v: float):
+        self.lib.check(self.lib.dll.wdpm_set_totaldrain(self._h, float(v)))
+
+    # -- block loop pieces
+    def begin_block(self, thres: float):
+        self.lib.check(self.lib.dll.wdpm_begin_block(self._h, thres))
+
+    def iterate(self, n: int):
+        self.lib.check(self.lib.dll.wdpm_iterate(self._h, n))
+
+    def single_pass(self, oi: int, oj: int):
+        self.lib.check(self.lib.dll.wdpm_pass(self._h, oi, oj))
+
+    def drain_outlet(self):
+        self.lib.check(self.lib.dll.wdpm_drain_outlet(self._h))
+
+    def max_diff(self, row_lo: int = 0, row_hi: int | None = None) -> float:
+        v = C.c_double()
+        hi = self.slab.rows if row_hi is None else row_hi
+        self.lib.check(self.lib.dll.wdpm_max_diff(self._h, row_lo, hi, C.byref(v)))
+        return v.value
+
+    def drain_stats(self):
+        a, b = C.c_double(), C.c_double()
+        self.lib.check(self.lib.dll.wdpm_drain_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def run_block(self, n_iter: int, thres: float) -> float:
+        v = C.c_double()
+        self.lib.check(self.lib.dll.wdpm_run_block(self._h, n_iter, thres, C.byref(v)))
+        return v.value
+
+    # -- plumbing
+    def water_ptr(self) -> int:
+        p = C.c_void_p()
+        self.lib.check(self.lib.dll.wdpm_water_ptr(self._h, C.byref(p)))
+        return p.value
+
+    def dem_ptr(self) -> int:
+        p = C.c_void_p()
+        self.lib.check(self.lib.dll.wdpm_dem_ptr(self._h, C.byref(p)))
+        return p.value
+
+    def set_stream(self, stream_handle: int):
+        self.lib.check(self.lib.dll.wdpm_set_stream(self._h, C.c_void_p(stream_handle)))
+
+    def synchronize(self):
+        self.lib.check(self.lib.dll.wdpm_synchronize(self._h))
+
+    def timing_reset(self):
+        self.lib.check(self.lib.dll.wdpm_timing_reset(self._h))
+
+    def timing(self):
+        n, ms = C.c_int64(), C.c_double()
+        self.lib.check(self.lib.dll.wdpm_timing_get(self._h, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+
+def load(path: str) -> Lib:
+    return Lib(path)
+
+
+_hip: Lib | None = None
+
+
+def load_hip() -> Lib:
+    """The product library.  Raises (never falls back) when it has not been built."""
+    global _hip
+    if _hip is None:
+        if not os.path.exists(HIP_LIB_PATH):
+            raise WdpmError(
+                f"HIP library {HIP_LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (or `make -C wdpm_amd/csrc`). There is no CPU fallback.")
+        _hip = Lib(HIP_LIB_PATH)
+    return _hip
