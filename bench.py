@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""bench.py — cell-updates/s of the WDPM Add module on a synthetic 16384 x 16384 DEM (BASELINE.json).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size 16384]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one iteration (all 9 colour passes) over the whole raster.  The timed region is one
+block of the reference's loop: threshold flush + snapshot, K iterations, max-|dw| reduction
+(src/WDPMCL.c:1055-1125,1239-1254), with the rasters already resident in HBM.  N > 1: row-block
+decomposition, one rank per GPU, halo refresh by RCCL send/recv (wdpm_amd/rowblock.py); total work
+is fixed, so scaling is strong.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_CELL_UPDATE = 24.0   # fp64 dem read + water read + water write
+HBM_PEAK_GBS = 8000.0               # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+THRES = 0.005 / 1000.0              # zero-depth threshold 0.005 mm
+ADD_M = 0.1                         # add 100 mm, runoff fraction 1.0
+MISSING = -99999.0
+
+
+def build_slab_inputs(lib, n, slab):
+    """padded dem / water rows [row0, row0+rows) of the config-4 workload"""
+    dem = lib.synth_dem(n, n)                      # integer-seeded generator, seed = size
+    ncp = n + 2
+    bd = np.full((slab.rows, ncp), MISSING)
+    lo, hi = max(slab.row0, 1), min(slab.row0 + slab.rows, n + 1)   # padded interior rows held
+    bd[lo - slab.row0:hi - slab.row0, 1:-1] = dem[lo - 1:hi - 1]
+    del dem
+    bw = np.where(bd > MISSING, ADD_M, 0.0)
+    return bd, bw
+
+
+def cpu_baseline(n=1024, iters=12):
+    """The CPU oracle (bit-equal port of the reference's serial path) timed on one host core on a
+    bounded sample of the same workload.  A reported baseline, never the product path."""
+    import subprocess
+    import wdpm_amd
+    so = os.path.join(ROOT, "oracle", "_build", "libwdpm_oracle.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "oracle"], stdout=subprocess.DEVNULL)
+    orc = wdpm_amd.load(so)
+    dem = orc.synth_dem(n, n)
+    bd = np.full((n + 2, n + 2), MISSING)
+    bd[1:-1, 1:-1] = dem
+    bw = np.where(bd > MISSING, ADD_M, 0.0)
+    with orc.context(module="add", nrows=n, ncols=n, missingvalue=MISSING) as c:
+        c.upload(bd, bw)
+        c.iterate(1)
+        t = time.perf_counter()
+        c.run_block(iters, THRES)
+        dt = time.perf_counter() - t
+    return {"value": n * n * iters / dt, "unit": "cell-updates/s", "cores": 1, "kind": "port",
+            "sample": f"oracle/wdpm_oracle.c, synthetic {n}x{n} all-wet add 100 mm, {iters} iterations, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--size", type=int, default=16384)
+    ap.add_argument("--exchange-every", type=int, default=int(os.environ.get("WDPM_EXCHANGE_EVERY", "4")))
+    ap.add_argument("--kernel", choices=["auto", "pass", "fused"], default="auto")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import wdpm_amd
+    from wdpm_amd.rowblock import DeviceTransport, RowBlockSolver
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    lib = wdpm_amd.load_hip()
+    n = args.size
+    kernel = {"auto": wdpm_amd.KERNEL_AUTO, "pass": wdpm_amd.KERNEL_PASS, "fused": wdpm_amd.KERNEL_FUSED}[args.kernel]
+    transport = DeviceTransport(dist, torch.device("cuda", local_rank)) if world > 1 else None
+    solver = RowBlockSolver(lib, "add", n, n, MISSING, rank=rank, nranks=world, exchange_every=args.exchange_every,
+                            transport=transport, dist=dist, device=local_rank, kernel=kernel)
+    solver.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    bd, bw = build_slab_inputs(lib, n, solver.slab)
+    solver.ctx.upload(bd, bw)
+    del bd, bw
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    solver.run_block(args.warmup, THRES)           # untimed warm-up steps
+    sync()
+    solver.ctx.timing_reset()
+    t0 = time.perf_counter()
+    max_diff = solver.run_block(args.steps, THRES) # exactly K timed steps
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    launches, kernel_ms = solver.ctx.timing()
+
+    if rank == 0:
+        cells = float(n) * n
+        value = cells * args.steps / dt
+        own_cells = float(solver.slab.own_hi - solver.slab.own_lo + 1) * n if world > 1 else cells
+        iter_ms = kernel_ms / max(args.steps, 1)     # device time of one iteration's stencil launch(es)
+        achieved = ALGO_BYTES_PER_CELL_UPDATE * own_cells / (iter_ms * 1e-3) / 1e9 if iter_ms > 0 else 0.0
+        out = {
+            "metric": "cell-updates/sec on Add module, 16k x 16k DEM",
+            "value": value, "unit": "cell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"synthetic {n}x{n} diamond-square DEM (seed {n}), Add 100 mm, rof 1.0, "
+                                   f"thres 0.005 mm, one block of {args.steps} iterations",
+                       "kernel": args.kernel, "decomposition": f"row-block x{world}" if world > 1 else "single GPU",
+                       "exchange_every": args.exchange_every if world > 1 else None,
+                       "max_diff_m": max_diff},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel_ms_per_iteration": iter_ms, "launches": launches,
+                         "job_frac": value * ALGO_BYTES_PER_CELL_UPDATE / 1e9 / (HBM_PEAK_GBS * world)},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    solver.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -57,7 +57,7 @@ typedef struct wdpm_params {
   int32_t slab_rows;    /* padded rows held (0 => all nrows+2 rows, slab_row0 must then be 0) */
   int32_t device;       /* HIP device ordinal (replaces create_device(), WDPMCL.c:80-121) */
   int32_t kernel;       /* WDPM_KERNEL_* */
-  int32_t reserved;
+  int32_t chunk_rows;   /* fused kernel: rows per marching chunk (multiple of 3); 0 = automatic */
   double  missingvalue; /* NODATA_VALUE, WDPMCL.c:554 */
 } wdpm_params;
 

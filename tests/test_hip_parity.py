@@ -1,0 +1,149 @@
+"""GPU parity tests: the HIP path, through the C ABI, against (i) the committed golden vectors of
+the unmodified reference and (ii) the CPU oracle on the same seeded inputs.  Bit-exact: the
+north_star tolerance (1e-4 mm) is slack, these tests demand 0 differing bits."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import wdpm_amd
+from conftest import GOLDEN
+from helpers import bits_equal, find_drain, n_bit_diff, pad, random_case, sha
+from test_oracle_golden import basin5_blocks, check_stencil_cases
+
+pytestmark = pytest.mark.gpu
+
+TOL_MM = 1e-4  # north_star: max abs depth difference in mm; we assert 0 and report against this
+
+
+class KernelLib:
+    """the hip Lib with a fixed kernel / chunk choice, so shared checkers can take it as `lib`"""
+
+    def __init__(self, lib, **kw):
+        self.lib, self.kw = lib, kw
+
+    def context(self, **kw):
+        kw = dict(self.kw, **kw)
+        return self.lib.context(**kw)
+
+
+@pytest.mark.parametrize("kernel,chunk", [(wdpm_amd.KERNEL_PASS, 0), (wdpm_amd.KERNEL_FUSED, 0),
+                                          (wdpm_amd.KERNEL_FUSED, 3), (wdpm_amd.KERNEL_FUSED, 12)])
+def test_golden_stencil_vectors(hip, stencil_cases, kernel, chunk):
+    z, index = stencil_cases
+    assert check_stencil_cases(KernelLib(hip, kernel=kernel, chunk_rows=chunk), z, index) > 100
+
+
+def _compare_with_oracle(hip, oracle, module, R, C, seed, iters, kernel, chunk=0, thres=None, **case_kw):
+    dem, water, miss = random_case(seed, R, C, **case_kw)
+    bd, bw = pad(dem, water, miss)
+    kw = dict(module=module, nrows=R, ncols=C, missingvalue=miss)
+    td0 = 0.0
+    if module == "drain":
+        dr, dc = find_drain(bd)
+        td0 = max(bw[dr, dc], 0.0)
+        kw.update(drainrow=dr, draincol=dc)
+    with hip.context(kernel=kernel, chunk_rows=chunk, **kw) as g, oracle.context(**kw) as o:
+        for c in (g, o):
+            c.upload(bd, bw)
+            c.totaldrain = td0
+        for n in iters:
+            if thres is not None:
+                mg, mo = g.run_block(n, thres), o.run_block(n, thres)
+                assert mg == mo
+            else:
+                g.iterate(n)
+                o.iterate(n)
+            wg, wo = g.download_water(), o.download_water()
+            nd = n_bit_diff(wg, wo)
+            maxmm = float(np.abs(wg - wo).max() * 1000)
+            assert nd == 0, f"{nd} cells differ, max |d| = {maxmm} mm (tolerance {TOL_MM} mm)"
+            assert g.totaldrain == o.totaldrain
+            if module == "drain":
+                assert g.drain_stats() == o.drain_stats()
+
+
+@pytest.mark.parametrize("kernel", [wdpm_amd.KERNEL_PASS, wdpm_amd.KERNEL_FUSED])
+@pytest.mark.parametrize("module", ["add", "drain"])
+@pytest.mark.parametrize("R,C,chunk", [(38, 398, 12), (100, 700, 0), (301, 170, 48), (64, 1100, 30), (5, 175, 3)])
+def test_random_rasters_match_oracle(hip, oracle, module, kernel, R, C, chunk):
+    _compare_with_oracle(hip, oracle, module, R, C, seed=R * 1000 + C, iters=(1, 2, 25), kernel=kernel, chunk=chunk)
+
+
+@pytest.mark.parametrize("module", ["add", "subtract", "drain"])
+def test_block_loop_matches_oracle(hip, oracle, module):
+    """flush + snapshot + iterations + max_diff (WDPMCL.c:1055-1073,1239-1254), thres > 0 and = 0"""
+    _compare_with_oracle(hip, oracle, module, 120, 333, seed=7, iters=(40, 40), kernel=wdpm_amd.KERNEL_FUSED,
+                         thres=0.005 / 1000)
+    _compare_with_oracle(hip, oracle, module, 61, 200, seed=8, iters=(30,), kernel=wdpm_amd.KERNEL_FUSED, thres=0.0)
+
+
+def test_all_missing_and_all_dry(hip, oracle):
+    _compare_with_oracle(hip, oracle, "add", 30, 200, seed=3, iters=(3,), kernel=wdpm_amd.KERNEL_FUSED,
+                         missing_frac=1.0)
+    _compare_with_oracle(hip, oracle, "add", 30, 200, seed=4, iters=(3,), kernel=wdpm_amd.KERNEL_FUSED,
+                         dry_frac=1.0)
+    _compare_with_oracle(hip, oracle, "add", 30, 200, seed=5, iters=(3,), kernel=wdpm_amd.KERNEL_FUSED,
+                         missing_frac=0.0, dry_frac=0.0)
+
+
+def test_basin5_add100_and_add300_state_hashes(hip, basin5):
+    """BASELINE configs 1-2 on the HIP path: full-precision state after 1000 / 3000 iterations equals
+    the unmodified reference's (sha256 of the fp64 raster), and so does the printed max diff."""
+    dem, hdr = basin5
+    z = np.load(os.path.join(GOLDEN, "basin5_state.npz"))
+    index = {m["name"]: m for m in json.loads(bytes(z["index_json"]).decode())}
+    with open(os.path.join(GOLDEN, "basin5_cli.json")) as f:
+        cli = json.load(f)
+    for add_mm, key in ((100.0, "cfg1_add100_k3000"), (300.0, None)):
+        bd, blocks = basin5_blocks(hip, dem, hdr["NODATA_VALUE"], add_mm, 3)
+        for k, (md, w) in zip((1000, 2000, 3000), blocks):
+            name = f"add{int(add_mm)}_k{k}"
+            if name in index:
+                assert sha(w) == index[name]["sha256"], name
+                assert bits_equal(w[::7], z[name + "_rows"])
+            if key:
+                want = cli[key]["blocks"][k // 1000 - 1]
+                assert want[0] == k and f"{md:8.3f}".strip() == want[1]
+
+
+def test_synthetic_1024_matches_oracle(hip, oracle):
+    """config-3 generator at 1024^2, add 100 mm, 60 iterations: HIP fused == oracle, bit for bit"""
+    n = 1024
+    dem = hip.synth_dem(n, n)
+    miss = -99999.0
+    bd, bw = pad(dem, np.full((n, n), 0.1), miss)
+    kw = dict(module="add", nrows=n, ncols=n, missingvalue=miss)
+    with hip.context(**kw) as g, oracle.context(**kw) as o:
+        g.upload(bd, bw)
+        o.upload(bd, bw)
+        mg, mo = g.run_block(60, 0.005 / 1000), o.run_block(60, 0.005 / 1000)
+        wg, wo = g.download_water(), o.download_water()
+        assert n_bit_diff(wg, wo) == 0, f"max |d| = {np.abs(wg - wo).max() * 1000} mm"
+        assert mg == mo
+
+
+@pytest.mark.parametrize("n,iters", [(4096, 20), (16384, 2)])
+def test_full_size_properties(hip, n, iters):
+    """BASELINE sizes, where the oracle is too slow: size-independent properties.
+    (1) the two independent HIP implementations (9 launches/iteration in place vs fused marching
+        window) agree bit for bit; (2) water volume is conserved to rounding; (3) depths stay >= 0."""
+    dem = hip.synth_dem(n, n)
+    miss = -99999.0
+    bd, bw = pad(dem, np.full((n, n), 0.1), miss)
+    del dem
+    kw = dict(module="add", nrows=n, ncols=n, missingvalue=miss)
+    with hip.context(kernel=wdpm_amd.KERNEL_FUSED, **kw) as f:
+        f.upload(bd, bw)
+        f.iterate(iters)
+        wf = f.download_water()
+    with hip.context(kernel=wdpm_amd.KERNEL_PASS, **kw) as p:
+        p.upload(bd, bw)
+        p.iterate(iters)
+        wp = p.download_water()
+    assert n_bit_diff(wf, wp) == 0
+    assert wf.min() >= 0.0
+    total0, total1 = 0.1 * n * n, float(wf.sum())
+    assert abs(total1 - total0) <= 1e-9 * total0
+    assert wf[0].max() == 0 and wf[-1].max() == 0 and wf[:, 0].max() == 0 and wf[:, -1].max() == 0

@@ -27,7 +27,7 @@ class Params(C.Structure):
         ("module", C.c_int32), ("nrows", C.c_int32), ("ncols", C.c_int32),
         ("drainrow", C.c_int32), ("draincol", C.c_int32),
         ("slab_row0", C.c_int32), ("slab_rows", C.c_int32),
-        ("device", C.c_int32), ("kernel", C.c_int32), ("reserved", C.c_int32),
+        ("device", C.c_int32), ("kernel", C.c_int32), ("chunk_rows", C.c_int32),
         ("missingvalue", C.c_double),
     ]
 
@@ -112,7 +112,7 @@ class Context:
 
     def __init__(self, lib: Lib, module, nrows: int, ncols: int, missingvalue: float,
                  drainrow: int = 0, draincol: int = 0, slab_row0: int = 0, slab_rows: int = 0,
-                 device: int = 0, kernel: int = KERNEL_AUTO):
+                 device: int = 0, kernel: int = KERNEL_AUTO, chunk_rows: int = 0):
         self.lib = lib
         if isinstance(module, str):
             module = MODULES[module]
@@ -122,7 +122,7 @@ class Context:
         self.slab = _Slab(slab_row0, slab_rows if slab_rows > 0 else nrows + 2)
         p = Params(module=module, nrows=nrows, ncols=ncols, drainrow=drainrow, draincol=draincol,
                    slab_row0=slab_row0, slab_rows=slab_rows, device=device, kernel=kernel,
-                   reserved=0, missingvalue=missingvalue)
+                   chunk_rows=chunk_rows, missingvalue=missingvalue)
         h = C.c_void_p()
         lib.check(lib.dll.wdpm_create(C.byref(h), C.byref(p)))
         self._h = h

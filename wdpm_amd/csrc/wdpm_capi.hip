@@ -1,0 +1,346 @@
+/*
+ * wdpm_capi.hip — the C ABI of include/wdpm.h implemented on HIP for gfx950.
+ *
+ * One context = one raster slab resident in one GPU's HBM for the context's lifetime:
+ *   dem      rows x (C+2) fp64   read-only after upload
+ *   water[2] rows x (C+2) fp64   ping-pong pair (the fused kernel reads one, writes the other)
+ *   old      rows x (C+2) fp64   snapshot for the convergence test
+ *   scal     {totaldrain, olddrain} fp64 + one uint64 reduction cell
+ * No CPU fallback: every compute entry point launches a HIP kernel or fails.
+ * Replaces the reference's OpenCL host path (src/WDPMCL.c:598-638, :1126-1236).
+ */
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/wdpm.h"
+#include "wdpm_kernels.h"
+
+static thread_local char g_err[512] = "";
+
+static int fail(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return 1;
+}
+
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+struct EventPair { hipEvent_t a, b; };
+
+struct wdpm_ctx {
+  wdpm_params p;
+  SlabGeom g;
+  size_t cells;
+  hipStream_t stream;
+  bool own_stream;
+  double *d_dem, *d_w[2], *d_old;
+  int cur;
+  double *d_scal;               /* [0] totaldrain, [1] olddrain */
+  unsigned long long *d_bits;   /* max-diff reduction cell */
+  double *h_pin;                /* pinned staging: 4 doubles */
+  std::vector<double> h_dem;    /* host copy of dem, kept only for wdpm_drain_stats */
+  int kernel;                   /* resolved WDPM_KERNEL_* */
+  /* stencil timing */
+  std::vector<EventPair> pending;
+  std::vector<EventPair> pool;
+  int64_t launches;
+  double ms;
+};
+
+extern "C" {
+
+const char *wdpm_last_error(void) { return g_err; }
+const char *wdpm_backend_name(void) { return "hip-gfx950"; }
+int wdpm_abi_version(void) { return WDPM_ABI_VERSION; }
+
+static int bind(wdpm_ctx *x) {
+  HIP_TRY(hipSetDevice(x->p.device));
+  return 0;
+}
+
+int wdpm_create(wdpm_ctx **out, const wdpm_params *p) {
+  if (!out || !p) return fail("wdpm_create: null argument");
+  if (p->nrows < 1 || p->ncols < 1) return fail("wdpm_create: bad raster size %d x %d", p->nrows, p->ncols);
+  if (p->module < WDPM_ADD || p->module > WDPM_DRAIN) return fail("wdpm_create: bad module %d", p->module);
+  if (p->slab_row0 < 0 || p->slab_row0 % 3 != 0) return fail("wdpm_create: slab_row0 must be a non-negative multiple of 3");
+  const int rows = p->slab_rows > 0 ? p->slab_rows : p->nrows + 2;
+  if (p->slab_row0 + rows > p->nrows + 2) return fail("wdpm_create: slab exceeds raster");
+  if (rows < 3) return fail("wdpm_create: a slab needs at least 3 rows");
+  if ((double)(p->nrows + 2) * (double)(p->ncols + 2) > 2.0e9) return fail("wdpm_create: raster too large for 32-bit cell indices per row block");
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (ndev < 1) return fail("wdpm_create: no HIP device (this library has no CPU fallback)");
+  if (p->device < 0 || p->device >= ndev) return fail("wdpm_create: device %d out of range (%d devices)", p->device, ndev);
+  HIP_TRY(hipSetDevice(p->device));
+
+  wdpm_ctx *x = new wdpm_ctx();
+  x->p = *p;
+  x->g.rows = rows;
+  x->g.ncp = p->ncols + 2;
+  x->g.row0 = p->slab_row0;
+  x->g.R = p->nrows;
+  x->g.C = p->ncols;
+  x->g.dr = p->drainrow - p->slab_row0;
+  x->g.dc = p->draincol;
+  x->g.miss = p->missingvalue;
+  if (p->module != WDPM_DRAIN) { x->g.dr = -1000000; x->g.dc = -1000000; }
+  x->cells = (size_t)rows * x->g.ncp;
+  x->kernel = p->kernel == WDPM_KERNEL_AUTO ? WDPM_KERNEL_FUSED : p->kernel;
+  x->cur = 0;
+  x->launches = 0;
+  x->ms = 0.0;
+  x->d_dem = x->d_w[0] = x->d_w[1] = x->d_old = nullptr;
+  x->d_scal = nullptr; x->d_bits = nullptr; x->h_pin = nullptr;
+  x->own_stream = true;
+  const size_t bytes = x->cells * sizeof(double);
+  hipError_t e = hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipMalloc(&x->d_dem, bytes);
+  if (e == hipSuccess) e = hipMalloc(&x->d_w[0], bytes);
+  if (e == hipSuccess) e = hipMalloc(&x->d_w[1], bytes);
+  if (e == hipSuccess) e = hipMalloc(&x->d_old, bytes);
+  if (e == hipSuccess) e = hipMalloc(&x->d_scal, 2 * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(&x->d_bits, sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipHostMalloc(&x->h_pin, 4 * sizeof(double));
+  if (e == hipSuccess) e = hipMemsetAsync(x->d_scal, 0, 2 * sizeof(double), x->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(x->d_old, 0, bytes, x->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(x->stream);
+  if (e != hipSuccess) {
+    fail("wdpm_create: device allocation failed: %s", hipGetErrorString(e));
+    wdpm_destroy(x);
+    return 1;
+  }
+  *out = x;
+  return 0;
+}
+
+void wdpm_destroy(wdpm_ctx *x) {
+  if (!x) return;
+  (void)hipSetDevice(x->p.device);
+  (void)hipStreamSynchronize(x->stream);
+  for (auto &ep : x->pending) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
+  for (auto &ep : x->pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
+  (void)hipFree(x->d_dem); (void)hipFree(x->d_w[0]); (void)hipFree(x->d_w[1]); (void)hipFree(x->d_old);
+  (void)hipFree(x->d_scal); (void)hipFree(x->d_bits);
+  if (x->h_pin) (void)hipHostFree(x->h_pin);
+  if (x->own_stream && x->stream) (void)hipStreamDestroy(x->stream);
+  delete x;
+}
+
+int wdpm_set_stream(wdpm_ctx *x, void *hip_stream) {
+  if (bind(x)) return 1;
+  HIP_TRY(hipStreamSynchronize(x->stream));
+  if (x->own_stream && x->stream) HIP_TRY(hipStreamDestroy(x->stream));
+  x->stream = (hipStream_t)hip_stream;
+  x->own_stream = false;
+  return 0;
+}
+
+int wdpm_synchronize(wdpm_ctx *x) {
+  if (bind(x)) return 1;
+  HIP_TRY(hipStreamSynchronize(x->stream));
+  return 0;
+}
+
+/* ---- data movement ---------------------------------------------------------------------- */
+int wdpm_upload(wdpm_ctx *x, const double *bigdem, const double *bigwater) {
+  if (!bigdem || !bigwater) return fail("wdpm_upload: null array");
+  if (bind(x)) return 1;
+  const size_t bytes = x->cells * sizeof(double);
+  HIP_TRY(hipMemcpyAsync(x->d_dem, bigdem, bytes, hipMemcpyHostToDevice, x->stream));
+  HIP_TRY(hipMemcpyAsync(x->d_w[x->cur], bigwater, bytes, hipMemcpyHostToDevice, x->stream));
+  HIP_TRY(hipStreamSynchronize(x->stream));
+  if (x->p.module == WDPM_DRAIN) x->h_dem.assign(bigdem, bigdem + x->cells);
+  return 0;
+}
+
+int wdpm_upload_water(wdpm_ctx *x, const double *bigwater) {
+  if (!bigwater) return fail("wdpm_upload_water: null array");
+  if (bind(x)) return 1;
+  HIP_TRY(hipMemcpyAsync(x->d_w[x->cur], bigwater, x->cells * sizeof(double), hipMemcpyHostToDevice, x->stream));
+  HIP_TRY(hipStreamSynchronize(x->stream));
+  return 0;
+}
+
+int wdpm_download_water(wdpm_ctx *x, double *bigwater) {
+  if (!bigwater) return fail("wdpm_download_water: null array");
+  if (bind(x)) return 1;
+  HIP_TRY(hipMemcpyAsync(bigwater, x->d_w[x->cur], x->cells * sizeof(double), hipMemcpyDeviceToHost, x->stream));
+  HIP_TRY(hipStreamSynchronize(x->stream));
+  return 0;
+}
+
+int wdpm_download_rows(wdpm_ctx *x, int32_t row, int32_t nrows, double *dst) {
+  if (row < 0 || nrows < 0 || row + nrows > x->g.rows || !dst) return fail("wdpm_download_rows: bad row range");
+  if (bind(x)) return 1;
+  HIP_TRY(hipMemcpyAsync(dst, x->d_w[x->cur] + (size_t)row * x->g.ncp, (size_t)nrows * x->g.ncp * sizeof(double),
+                         hipMemcpyDeviceToHost, x->stream));
+  HIP_TRY(hipStreamSynchronize(x->stream));
+  return 0;
+}
+
+int wdpm_upload_rows(wdpm_ctx *x, int32_t row, int32_t nrows, const double *src) {
+  if (row < 0 || nrows < 0 || row + nrows > x->g.rows || !src) return fail("wdpm_upload_rows: bad row range");
+  if (bind(x)) return 1;
+  HIP_TRY(hipMemcpyAsync(x->d_w[x->cur] + (size_t)row * x->g.ncp, src, (size_t)nrows * x->g.ncp * sizeof(double),
+                         hipMemcpyHostToDevice, x->stream));
+  HIP_TRY(hipStreamSynchronize(x->stream));
+  return 0;
+}
+
+int wdpm_set_totaldrain(wdpm_ctx *x, double v) {
+  if (bind(x)) return 1;
+  x->h_pin[0] = v;
+  HIP_TRY(hipMemcpyAsync(x->d_scal, x->h_pin, sizeof(double), hipMemcpyHostToDevice, x->stream));
+  HIP_TRY(hipStreamSynchronize(x->stream));
+  return 0;
+}
+
+int wdpm_get_totaldrain(wdpm_ctx *x, double *v) {
+  if (bind(x)) return 1;
+  HIP_TRY(hipMemcpyAsync(x->h_pin, x->d_scal, sizeof(double), hipMemcpyDeviceToHost, x->stream));
+  HIP_TRY(hipStreamSynchronize(x->stream));
+  *v = x->h_pin[0];
+  return 0;
+}
+
+int wdpm_water_ptr(wdpm_ctx *x, void **ptr) { *ptr = x->d_w[x->cur]; return 0; }
+int wdpm_dem_ptr(wdpm_ctx *x, void **ptr) { *ptr = x->d_dem; return 0; }
+
+/* ---- block loop ------------------------------------------------------------------------- */
+int wdpm_begin_block(wdpm_ctx *x, double thres) {
+  if (bind(x)) return 1;
+  HIP_TRY(wdpm_launch_flush_snapshot(x->d_w[x->cur], x->d_old, x->cells, thres, x->stream));
+  HIP_TRY(hipMemcpyAsync(x->d_scal + 1, x->d_scal, sizeof(double), hipMemcpyDeviceToDevice, x->stream)); /* olddrain */
+  return 0;
+}
+
+static int fold_timing(wdpm_ctx *x) {
+  for (auto &ep : x->pending) {
+    HIP_TRY(hipEventSynchronize(ep.b));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, ep.a, ep.b));
+    x->ms += ms;
+    x->pool.push_back(ep);
+  }
+  x->pending.clear();
+  return 0;
+}
+
+static int one_pass(wdpm_ctx *x, int oi, int oj) {
+  HIP_TRY(wdpm_launch_pass(x->p.module, x->d_w[x->cur], x->d_dem, x->g, oi, oj, x->d_scal, x->stream));
+  return 0;
+}
+
+int wdpm_pass(wdpm_ctx *x, int32_t oi, int32_t oj) {
+  if (oi < 1 || oi > 3 || oj < 1 || oj > 3) return fail("wdpm_pass: oi,oj must be in 1..3");
+  if (bind(x)) return 1;
+  return one_pass(x, oi, oj);
+}
+
+int wdpm_drain_outlet(wdpm_ctx *x) {
+  if (x->p.module != WDPM_DRAIN) return 0;
+  if (bind(x)) return 1;
+  HIP_TRY(wdpm_launch_drain_outlet(x->d_w[x->cur], x->d_dem, x->g, x->d_scal, x->stream));
+  return 0;
+}
+
+int wdpm_iterate(wdpm_ctx *x, int32_t n_iter) {
+  if (n_iter < 0) return fail("wdpm_iterate: negative iteration count");
+  if (n_iter == 0) return 0;
+  if (bind(x)) return 1;
+  if (x->pending.size() >= 256 && fold_timing(x)) return 1;
+  EventPair ep;
+  if (!x->pool.empty()) { ep = x->pool.back(); x->pool.pop_back(); }
+  else { HIP_TRY(hipEventCreate(&ep.a)); HIP_TRY(hipEventCreate(&ep.b)); }
+  HIP_TRY(hipEventRecord(ep.a, x->stream));
+  for (int it = 0; it < n_iter; it++) {
+    if (x->kernel == WDPM_KERNEL_FUSED) {
+      HIP_TRY(wdpm_launch_fused(x->p.module, x->d_w[x->cur], x->d_w[x->cur ^ 1], x->d_dem, x->g, x->p.chunk_rows, x->d_scal, x->stream));
+      x->cur ^= 1;
+      x->launches += 1;
+    } else {
+      for (int oi = 1; oi <= 3; oi++)
+        for (int oj = 1; oj <= 3; oj++)
+          if (one_pass(x, oi, oj)) return 1;
+      x->launches += 9;
+    }
+    if (x->p.module == WDPM_DRAIN)
+      HIP_TRY(wdpm_launch_drain_outlet(x->d_w[x->cur], x->d_dem, x->g, x->d_scal, x->stream));
+  }
+  HIP_TRY(hipEventRecord(ep.b, x->stream));
+  x->pending.push_back(ep);
+  return 0;
+}
+
+int wdpm_max_diff(wdpm_ctx *x, int32_t row_lo, int32_t row_hi, double *out) {
+  if (row_lo < 0 || row_hi > x->g.rows || row_lo > row_hi || !out) return fail("wdpm_max_diff: bad row range");
+  if (bind(x)) return 1;
+  HIP_TRY(wdpm_launch_max_diff(x->d_w[x->cur], x->d_old, x->d_dem, x->g, row_lo, row_hi, x->d_bits, x->stream));
+  HIP_TRY(hipMemcpyAsync(x->h_pin, x->d_bits, sizeof(double), hipMemcpyDeviceToHost, x->stream));
+  HIP_TRY(hipStreamSynchronize(x->stream));
+  *out = x->h_pin[0];
+  return 0;
+}
+
+/* WDPMCL.c:1257-1268.  final_sum is the reference's sequential row-major sum; a parallel device
+ * sum would round differently, so the raster comes to the host for it (drain module only, once
+ * per block of iterations). */
+int wdpm_drain_stats(wdpm_ctx *x, double *diffdrain, double *final_sum) {
+  if (bind(x)) return 1;
+  if (diffdrain) {
+    HIP_TRY(hipMemcpyAsync(x->h_pin, x->d_scal, 2 * sizeof(double), hipMemcpyDeviceToHost, x->stream));
+    HIP_TRY(hipStreamSynchronize(x->stream));
+    *diffdrain = fabs(x->h_pin[0] - x->h_pin[1]);
+  }
+  if (final_sum) {
+    if (x->h_dem.size() != x->cells) {
+      x->h_dem.resize(x->cells);
+      HIP_TRY(hipMemcpyAsync(x->h_dem.data(), x->d_dem, x->cells * sizeof(double), hipMemcpyDeviceToHost, x->stream));
+    }
+    std::vector<double> w(x->cells);
+    HIP_TRY(hipMemcpyAsync(w.data(), x->d_w[x->cur], x->cells * sizeof(double), hipMemcpyDeviceToHost, x->stream));
+    HIP_TRY(hipStreamSynchronize(x->stream));
+    double s = 0;
+    const double miss = x->g.miss;
+    for (size_t i = 0; i < x->cells; i++)
+      if (x->h_dem[i] > miss) s += w[i];
+    *final_sum = s;
+  }
+  return 0;
+}
+
+int wdpm_run_block(wdpm_ctx *x, int32_t n_iter, double thres, double *max_diff) {
+  if (wdpm_begin_block(x, thres)) return 1;
+  if (wdpm_iterate(x, n_iter)) return 1;
+  return wdpm_max_diff(x, 0, x->g.rows, max_diff);
+}
+
+int wdpm_timing_reset(wdpm_ctx *x) {
+  if (bind(x)) return 1;
+  if (fold_timing(x)) return 1;
+  x->launches = 0;
+  x->ms = 0.0;
+  return 0;
+}
+
+int wdpm_timing_get(wdpm_ctx *x, int64_t *launches, double *ms) {
+  if (bind(x)) return 1;
+  if (fold_timing(x)) return 1;
+  if (launches) *launches = x->launches;
+  if (ms) *ms = x->ms;
+  return 0;
+}
+
+} /* extern "C" */

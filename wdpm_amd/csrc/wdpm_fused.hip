@@ -1,0 +1,327 @@
+/*
+ * wdpm_fused.hip — one whole WDPM iteration (all 9 colour passes, reference src/WDPMCL.c:1094-1106,
+ * kernels runoff.cl:137-183) in ONE launch, reading each raster from HBM once and writing the
+ * water raster once: 24 B per cell-update, the algorithmic minimum.
+ *
+ * Design (DESIGN.md §4 has the derivation and the numpy model tests/fused_model.py checks the
+ * schedule against the oracle):
+ *
+ *  - A wave64 is the unit of work; waves never synchronise with each other (no LDS, no barriers).
+ *    Lane m owns raster columns c0+3m .. c0+3m+2, so a wave covers a 192-column strip and a
+ *    64-lane row load/store is one contiguous 1536-byte segment.
+ *  - The wave marches down a chunk of rows with a 7-row window held in registers (dem + water,
+ *    3 columns per lane).  Each step loads 3 new rows and applies, in this order, row alignment
+ *    oi=1 to rows 3n..3n+2, oi=2 to rows 3n-2..3n, oi=3 to rows 3n-4..3n-2 — a skew that respects
+ *    every dependency of the reference's pass order, because a 3x3 block of pass (oi,oj) only
+ *    needs its nine cells to have finished all earlier passes.  Rows 3n-4..3n-2 are then final
+ *    and are stored.
+ *  - Within a row alignment the three column alignments oj=1,2,3 shift the blocks right by one
+ *    column each: the lane borrows column 0 (then column 1) of lane m+1 with a DPP wave_shl:1
+ *    register move, updates it, and hands both back with wave_shr:1.  No LDS traffic.
+ *  - Information moves at most 8 columns left / 16 right and 2 rows up / 4 down per iteration, so
+ *    a wave's 192 x (H+6) input trapezoid yields a 168 x H exact output; neighbouring waves
+ *    recompute the overlap (redundant, bit-identical work) instead of communicating.
+ *  - Cells with bigdem <= missingvalue and cells outside the slab are held as dem = +inf: as a
+ *    neighbour this makes ht_diff -inf/NaN, so `ht_diff > 0` is false with no extra test
+ *    (WDPMCL.c:1944); as a centre the gate `dem < +inf` replaces `bigdem > missingvalue` (:1099).
+ *
+ * Results are bit-identical to the serial reference: same operands, same order, fp64, no FMA.
+ */
+#include "wdpm_kernels.h"
+#include "wdpm_stencil.h"
+
+#include <cstdlib>
+
+namespace {
+
+constexpr int kLanes = 64;
+constexpr int kStripIn = 3 * kLanes;                     // 192 columns loaded per wave
+constexpr int kHaloL = 8, kHaloR = 16;                   // columns lost per fused iteration
+constexpr int kStripOut = kStripIn - kHaloL - kHaloR;    // 168 columns stored per wave
+
+#define WDPM_INF (__builtin_inf())
+
+/* value held by lane+1; lane 63 receives `fill`.  v_mov_b32_dpp wave_shl:1 */
+__device__ __forceinline__ double lane_next(const double v, const double fill) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(__double2loint(fill), lo, 0x130, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), hi, 0x130, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+
+/* value held by lane-1; lane 0 keeps `keep`.  v_mov_b32_dpp wave_shr:1 */
+__device__ __forceinline__ double lane_prev(const double v, const double keep) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(__double2loint(keep), lo, 0x138, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(__double2hiint(keep), hi, 0x138, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_read(const double v, const int src_lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
+}
+
+/* drain-module bookkeeping carried through the passes (compiles away for add/subtract) */
+struct DrainState {
+  double td;      // running totaldrain (wave-uniform value, one copy per lane)
+  bool hit;       // this lane drained in the current pass
+};
+
+/* one neighbour step of runoffd() including its outlet branch (WDPMCL.c:1975-2002) */
+__device__ __forceinline__ void step_drain(const double dc, double &wc, const double dn, double &wn,
+                                           const bool gate, const bool is_outlet, DrainState &ds) {
+  const bool hit = gate & is_outlet & (dn < WDPM_INF);   // :1976,1980
+  const double td2 = (ds.td + wn) + wc;                   // :1982
+  ds.td = hit ? td2 : ds.td;
+  ds.hit = ds.hit | hit;
+  wn = hit ? 0.0 : wn;                                    // :1983
+  wc = hit ? 0.0 : wc;                                    // :1984
+  flow_drain(dc, wc, dn, wn, gate & !hit);                // :1988-2000
+}
+
+/* one 3x3 block of one colour pass: centre (1,1), neighbours in row-major order */
+template <int MODULE>
+__device__ __forceinline__ void block_update(
+    double &w00, double &w01, double &w02, double &w10, double &w11, double &w12, double &w20, double &w21,
+    double &w22, const double d00, const double d01, const double d02, const double d10, const double d11,
+    const double d12, const double d20, const double d21, const double d22,
+    const bool rd0, const bool rd1, const bool rd2, const bool cd0, const bool cd1, const bool cd2,
+    DrainState &ds) {
+  double wc = w11;
+  bool gate = (wc > 0.0) & (d11 < WDPM_INF);            // WDPMCL.c:1099
+  if (MODULE == 2) {
+    gate = gate & !(rd1 & cd1);                          // :1082 the outlet is never a centre
+    ds.hit = false;
+    step_drain(d11, wc, d00, w00, gate, rd0 & cd0, ds);
+    step_drain(d11, wc, d01, w01, gate, rd0 & cd1, ds);
+    step_drain(d11, wc, d02, w02, gate, rd0 & cd2, ds);
+    step_drain(d11, wc, d10, w10, gate, rd1 & cd0, ds);
+    step_drain(d11, wc, d12, w12, gate, rd1 & cd2, ds);
+    step_drain(d11, wc, d20, w20, gate, rd2 & cd0, ds);
+    step_drain(d11, wc, d21, w21, gate, rd2 & cd1, ds);
+    step_drain(d11, wc, d22, w22, gate, rd2 & cd2, ds);
+    // at most one lane of the wave holds the outlet in this pass: make its totaldrain the wave's
+    const unsigned long long m = __ballot(ds.hit);
+    if (m) ds.td = wave_read(ds.td, __ffsll((long long)m) - 1);
+  } else {
+    flow_add(d11, wc, d00, w00, gate);
+    flow_add(d11, wc, d01, w01, gate);
+    flow_add(d11, wc, d02, w02, gate);
+    flow_add(d11, wc, d10, w10, gate);
+    flow_add(d11, wc, d12, w12, gate);
+    flow_add(d11, wc, d20, w20, gate);
+    flow_add(d11, wc, d21, w21, gate);
+    flow_add(d11, wc, d22, w22, gate);
+  }
+  w11 = wc;
+}
+
+/* the three column alignments oj = 1,2,3 of one row alignment, on window slots S0..S0+2 */
+template <int MODULE, int S0>
+__device__ __forceinline__ void stage(double (&W)[7][3], const double (&D)[7][3], const int row_s0,
+                                      const int drain_row, const bool (&cdr)[5], DrainState &ds) {
+  const bool rd0 = MODULE == 2 && row_s0 == drain_row;
+  const bool rd1 = MODULE == 2 && row_s0 + 1 == drain_row;
+  const bool rd2 = MODULE == 2 && row_s0 + 2 == drain_row;
+  constexpr int a = S0, b = S0 + 1, c = S0 + 2;
+  // oj = 1: own columns 0,1,2
+  block_update<MODULE>(W[a][0], W[a][1], W[a][2], W[b][0], W[b][1], W[b][2], W[c][0], W[c][1], W[c][2],
+                       D[a][0], D[a][1], D[a][2], D[b][0], D[b][1], D[b][2], D[c][0], D[c][1], D[c][2],
+                       rd0, rd1, rd2, cdr[0], cdr[1], cdr[2], ds);
+  // oj = 2: own columns 1,2 + column 0 of the next lane
+  double wa0 = lane_next(W[a][0], 0.0), wb0 = lane_next(W[b][0], 0.0), wc0 = lane_next(W[c][0], 0.0);
+  const double da0 = lane_next(D[a][0], WDPM_INF), db0 = lane_next(D[b][0], WDPM_INF),
+               dc0 = lane_next(D[c][0], WDPM_INF);
+  block_update<MODULE>(W[a][1], W[a][2], wa0, W[b][1], W[b][2], wb0, W[c][1], W[c][2], wc0,
+                       D[a][1], D[a][2], da0, D[b][1], D[b][2], db0, D[c][1], D[c][2], dc0,
+                       rd0, rd1, rd2, cdr[1], cdr[2], cdr[3], ds);
+  // oj = 3: own column 2 + columns 0,1 of the next lane
+  double wa1 = lane_next(W[a][1], 0.0), wb1 = lane_next(W[b][1], 0.0), wc1 = lane_next(W[c][1], 0.0);
+  const double da1 = lane_next(D[a][1], WDPM_INF), db1 = lane_next(D[b][1], WDPM_INF),
+               dc1 = lane_next(D[c][1], WDPM_INF);
+  block_update<MODULE>(W[a][2], wa0, wa1, W[b][2], wb0, wb1, W[c][2], wc0, wc1,
+                       D[a][2], da0, da1, D[b][2], db0, db1, D[c][2], dc0, dc1,
+                       rd0, rd1, rd2, cdr[2], cdr[3], cdr[4], ds);
+  // hand the borrowed columns back to lane+1; lane 0 keeps its own (nothing to its left)
+  W[a][0] = lane_prev(wa0, W[a][0]);  W[a][1] = lane_prev(wa1, W[a][1]);
+  W[b][0] = lane_prev(wb0, W[b][0]);  W[b][1] = lane_prev(wb1, W[b][1]);
+  W[c][0] = lane_prev(wc0, W[c][0]);  W[c][1] = lane_prev(wc1, W[c][1]);
+}
+
+template <int MODULE>
+__global__ void __launch_bounds__(256)
+fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout,
+                       const double *__restrict__ dem, const SlabGeom g, const int nstrips,
+                       const int nitems, const int H, double *__restrict__ totaldrain) {
+  const int lane = threadIdx.x & 63;
+  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= nitems) return;                       // wave-uniform
+  const int strip = item % nstrips, chunk = item / nstrips;
+  const int c0 = kStripOut * strip;
+  const int oc_lo = strip == 0 ? 0 : c0 + kHaloL;
+  const int oc_hi = c0 + kStripIn - 1 - kHaloR;
+  const int A = H * chunk;
+  const int nsteps = H / 3 + 2;
+  const int or_lo = chunk == 0 ? 0 : A + 2;
+  int or_hi = H * (chunk + 1) + 1;
+  if (or_hi > g.rows - 1) or_hi = g.rows - 1;
+
+  const int colb = c0 + 3 * lane;
+  bool colok[3], stok[3];
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    colok[j] = colb + j < g.ncp;
+    stok[j] = colok[j] && colb + j >= oc_lo && colb + j <= oc_hi;
+  }
+  bool cdr[5];
+#pragma unroll
+  for (int j = 0; j < 5; j++) cdr[j] = MODULE == 2 && colb + j == g.dc;
+  DrainState ds;
+  ds.td = MODULE == 2 ? *totaldrain : 0.0;
+  ds.hit = false;
+
+  double W[7][3], D[7][3];
+#pragma unroll
+  for (int k = 0; k < 7; k++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) { W[k][j] = 0.0; D[k][j] = WDPM_INF; }
+
+  // raw prefetch registers for the next step's three rows
+  double NW[3][3], ND[3][3];
+  bool nrow_ok[3];
+  auto prefetch = [&](const int r0) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const int r = r0 + i;
+      nrow_ok[i] = r < g.rows;
+      const size_t rowoff = (size_t)(nrow_ok[i] ? r : 0) * g.ncp;
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        const size_t off = rowoff + (colok[j] ? colb + j : 0);
+        NW[i][j] = win[off];
+        ND[i][j] = dem[off];
+      }
+    }
+  };
+  prefetch(A);
+
+  for (int n = 0; n < nsteps; n++) {
+    // consume the prefetched rows into window slots 4..6 (invalid cells become dem=+inf, w=0)
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        const bool ok = nrow_ok[i] & colok[j];
+        W[4 + i][j] = ok ? NW[i][j] : 0.0;
+        D[4 + i][j] = (ok & (ND[i][j] > g.miss)) ? ND[i][j] : WDPM_INF;
+      }
+    if (n + 1 < nsteps) prefetch(A + 3 * (n + 1));
+
+    const int rbase = A + 3 * n - 4;                 // slab row of window slot 0
+    stage<MODULE, 4>(W, D, rbase + 4, g.dr, cdr, ds);   // oi = 1 on rows 3n   .. 3n+2
+    stage<MODULE, 2>(W, D, rbase + 2, g.dr, cdr, ds);   // oi = 2 on rows 3n-2 .. 3n
+    stage<MODULE, 0>(W, D, rbase + 0, g.dr, cdr, ds);   // oi = 3 on rows 3n-4 .. 3n-2
+
+    // rows 3n-4 .. 3n-2 have now seen all nine passes
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const int r = rbase + i;
+      if (r >= or_lo && r <= or_hi) {               // wave-uniform
+        const size_t rowoff = (size_t)r * g.ncp + colb;
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+          if (stok[j]) wout[rowoff + j] = W[i][j];
+      }
+    }
+    // slide the window down three rows
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) { W[k][j] = W[k + 3][j]; D[k][j] = D[k + 3][j]; }
+  }
+
+  if (MODULE == 2) {
+    // exactly one wave owns the outlet cell in its exact output region; it saw every pass that
+    // touches the outlet, in the reference's order, so its totaldrain is the raster's.
+    const int dcol_hi = oc_hi < g.ncp - 1 ? oc_hi : g.ncp - 1;
+    const bool owner = g.dr >= or_lo && g.dr <= or_hi && g.dc >= oc_lo && g.dc <= dcol_hi;
+    if (owner && lane == 0) *totaldrain = ds.td;
+  }
+}
+
+__global__ void dpp_probe_kernel(int *out) {
+  const int lane = threadIdx.x;
+  const double v = (double)lane;
+  out[lane] = (int)lane_next(v, -1.0);
+  out[64 + lane] = (int)lane_prev(v, -2.0);
+}
+
+}  // namespace
+
+/* chunk height in rows (multiple of 3).  Default: enough (strip, chunk) work items to give every
+ * SIMD of the 256 CUs several waves, but chunks tall enough that the 6-row warm-up is small. */
+static int pick_chunk_rows(const int rows, const int nstrips, const int override_rows) {
+  static int env_h = -1;
+  if (env_h < 0) {
+    const char *e = getenv("WDPM_CHUNK_ROWS");
+    env_h = e ? atoi(e) : 0;
+  }
+  int H;
+  if (override_rows >= 3) {
+    H = override_rows / 3 * 3;
+  } else if (env_h >= 3) {
+    H = env_h / 3 * 3;
+  } else {
+    const int target_items = 256 * 4 * 4;          // CUs x SIMDs x waves
+    int nch = (target_items + nstrips - 1) / nstrips;
+    if (nch < 1) nch = 1;
+    H = ((rows + nch - 1) / nch + 2) / 3 * 3;
+    if (H < 48) H = 48;
+  }
+  if (H > rows) H = (rows + 2) / 3 * 3;
+  if (H < 3) H = 3;
+  return H;
+}
+
+static hipError_t dpp_selfcheck(hipStream_t s) {
+  static int state = 0;   // 0 unknown, 1 ok, -1 bad
+  if (state == 1) return hipSuccess;
+  if (state == -1) return hipErrorUnknown;
+  int *d = nullptr;
+  int h[128];
+  hipError_t e = hipMalloc(&d, sizeof h);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(dpp_probe_kernel, dim3(1), dim3(64), 0, s, d);
+  e = hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFree(d);
+  if (e != hipSuccess) return e;
+  bool ok = true;
+  for (int l = 0; l < 64; l++) {
+    ok = ok && h[l] == (l < 63 ? l + 1 : -1);
+    ok = ok && h[64 + l] == (l > 0 ? l - 1 : -2);
+  }
+  state = ok ? 1 : -1;
+  return ok ? hipSuccess : hipErrorUnknown;
+}
+
+hipError_t wdpm_launch_fused(int module, const double *w_in, double *w_out, const double *dem,
+                             const SlabGeom &g, int chunk_rows, double *totaldrain, hipStream_t s) {
+  hipError_t e = dpp_selfcheck(s);
+  if (e != hipSuccess) return e;
+  int nstrips = 1;
+  if (g.ncp > kStripIn - kHaloR) nstrips = (g.ncp - (kStripIn - kHaloR) + kStripOut - 1) / kStripOut + 1;
+  const int H = pick_chunk_rows(g.rows, nstrips, chunk_rows);
+  // chunk i stores rows [H*i+2 (0 for i=0), H*(i+1)+1]; the last must reach row rows-1
+  int nchunks = (g.rows - 2 + H - 1) / H;
+  if (nchunks < 1) nchunks = 1;
+  const int nitems = nstrips * nchunks;
+  const dim3 grid((nitems + 3) / 4), block(256);
+  if (module == 2)
+    hipLaunchKernelGGL(fused_iteration_kernel<2>, grid, block, 0, s, w_in, w_out, dem, g, nstrips, nitems, H, totaldrain);
+  else
+    hipLaunchKernelGGL(fused_iteration_kernel<0>, grid, block, 0, s, w_in, w_out, dem, g, nstrips, nitems, H, totaldrain);
+  return hipGetLastError();
+}

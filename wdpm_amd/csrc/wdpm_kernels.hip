@@ -1,0 +1,179 @@
+/*
+ * wdpm_kernels.hip — gfx950 kernels for the WDPM block loop that are not the fused iteration:
+ *   - one colour pass per launch (the unit the reference launches, runoff.cl:137-183)
+ *   - drain() outlet emptying (WDPMCL.c:1859-1897)
+ *   - threshold flush + snapshot (WDPMCL.c:1055-1073)
+ *   - max |w - oldw| over valid cells (WDPMCL.c:1239-1254): wave64 shuffle reduction, one
+ *     atomicMax per workgroup on the uint64 image of the (non-negative) double
+ * Row-major padded rasters; all arithmetic fp64 in the reference's order; compiled with
+ * -ffp-contract=off (there are no products to contract, x/8.0 is written x*0.125 which is the
+ * same correctly-rounded value, subnormals included).
+ */
+#include "wdpm_kernels.h"
+#include "wdpm_stencil.h"
+
+// ---------------------------------------------------------------------------------------------
+// one colour pass: one thread per 3x3 block of the pass, in place
+// ---------------------------------------------------------------------------------------------
+template <int MODULE>
+__global__ void __launch_bounds__(256)
+pass_kernel(double *__restrict__ w, const double *__restrict__ dem, SlabGeom g, int oi, int oj,
+            double *totaldrain) {
+  const int bc = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int br = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int c = oj + 3 * bc;   // centre column (padded coords)
+  const int r = oi + 3 * br;   // centre row, slab-local (row0 % 3 == 0 keeps the colour alignment)
+  if (c > g.C || r > g.rows - 2 || r + g.row0 > g.R) return;
+  const size_t ic = (size_t)r * g.ncp + c;
+  const double dc_ = dem[ic];
+  double wc = w[ic];
+  if (!(wc > 0.0 && dc_ > g.miss)) return;          // WDPMCL.c:1099
+  if (MODULE == 2 && r == g.dr && c == g.dc) return; // WDPMCL.c:1082
+  double td = 0.0;
+  bool drained = false;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const int rr = r + nb_dr(k), cc = c + nb_dc(k);
+    const size_t in = (size_t)rr * g.ncp + cc;
+    const double dn = dem[in];
+    if (!(dn > g.miss)) continue;
+    double wn = w[in];
+    if (MODULE == 2) {
+      if (rr == g.dr && cc == g.dc) {
+        // WDPMCL.c:1980-1985: everything in the centre and in the drain cell leaves the raster
+        td = (*totaldrain + wn) + wc;
+        drained = true;
+        wn = 0.0;
+        wc = 0.0;
+      } else {
+        flow_drain(dc_, wc, dn, wn);
+      }
+    } else {
+      flow_add(dc_, wc, dn, wn);
+    }
+    w[in] = wn;
+  }
+  w[ic] = wc;
+  if (MODULE == 2 && drained) *totaldrain = td;
+}
+
+hipError_t wdpm_launch_pass(int module, double *w, const double *dem, const SlabGeom &g, int oi, int oj,
+                            double *totaldrain, hipStream_t s) {
+  const int nbc = (g.C - oj) / 3 + 1;               // centres oj, oj+3, ... <= C
+  int rmax = g.rows - 2;
+  if (g.R - g.row0 < rmax) rmax = g.R - g.row0;
+  if (rmax < oi || g.C < oj) return hipSuccess;
+  const int nbr = (rmax - oi) / 3 + 1;
+  dim3 grid((nbc + 63) / 64, (nbr + 3) / 4);
+  if (module == 2)
+    hipLaunchKernelGGL(pass_kernel<2>, grid, dim3(256), 0, s, w, dem, g, oi, oj, totaldrain);
+  else
+    hipLaunchKernelGGL(pass_kernel<0>, grid, dim3(256), 0, s, w, dem, g, oi, oj, totaldrain);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// drain(): totaldrain += sum of positive water on valid cells of the outlet's 3x3 (row-major
+// order, starting from 0), then zero all nine cells.  One lane; once per iteration.
+// ---------------------------------------------------------------------------------------------
+__global__ void drain_outlet_kernel(double *__restrict__ w, const double *__restrict__ dem, SlabGeom g,
+                                    double *totaldrain) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double s = 0.0;
+  for (int i = -1; i <= 1; i++)
+    for (int j = -1; j <= 1; j++) {
+      const size_t k = (size_t)(g.dr + i) * g.ncp + (g.dc + j);
+      const double wk = w[k];
+      if (dem[k] > g.miss && wk > 0) s += wk;   // WDPMCL.c:1877-1884
+    }
+  for (int i = -1; i <= 1; i++)
+    for (int j = -1; j <= 1; j++) w[(size_t)(g.dr + i) * g.ncp + (g.dc + j)] = 0.0;  // :1885-1889
+  *totaldrain = *totaldrain + s;                 // :1089
+}
+
+hipError_t wdpm_launch_drain_outlet(double *w, const double *dem, const SlabGeom &g, double *totaldrain,
+                                    hipStream_t s) {
+  if (g.dr < 1 || g.dr > g.rows - 2 || g.dc < 1 || g.dc > g.ncp - 2) return hipSuccess;
+  hipLaunchKernelGGL(drain_outlet_kernel, dim3(1), dim3(64), 0, s, w, dem, g, totaldrain);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// flush + snapshot: w<thres -> 0 over the whole padded slab, then old = w.  16 B per lane.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+flush_snapshot_kernel(double *__restrict__ w, double *__restrict__ old, size_t cells, double thres) {
+  const size_t npair = cells / 2;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  double2 *w2 = reinterpret_cast<double2 *>(w);
+  double2 *o2 = reinterpret_cast<double2 *>(old);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npair; i += stride) {
+    double2 v = w2[i];
+    if (v.x < thres) v.x = 0;   // WDPMCL.c:1059-1062 (note: NaN and values >= thres are kept)
+    if (v.y < thres) v.y = 0;
+    w2[i] = v;
+    o2[i] = v;
+  }
+  if ((cells & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    double v = w[cells - 1];
+    if (v < thres) v = 0;
+    w[cells - 1] = v;
+    old[cells - 1] = v;
+  }
+}
+
+hipError_t wdpm_launch_flush_snapshot(double *w, double *old, size_t cells, double thres, hipStream_t s) {
+  size_t blocks = (cells / 2 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(flush_snapshot_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w, old, cells, thres);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// max_diff: per-lane running max with the reference's "if (d > m) m = d" (NaN never wins),
+// wave64 xor-shuffle reduction, LDS across the 4 waves, one atomicMax per workgroup.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_max(double m) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const double o = __shfl_xor(m, off, 64);
+    if (o > m) m = o;
+  }
+  return m;
+}
+
+__global__ void __launch_bounds__(256)
+max_diff_kernel(const double *__restrict__ w, const double *__restrict__ old, const double *__restrict__ dem,
+                size_t first, size_t last, double miss, int seed_cell0, unsigned long long *result_bits) {
+  __shared__ double part[4];
+  double m = 0.0;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = first + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < last; i += stride) {
+    if (dem[i] > miss || (seed_cell0 && i == 0)) {   // WDPMCL.c:1245 seeds with diff[0][0]
+      const double d = fabs(w[i] - old[i]);
+      if (d > m) m = d;
+    }
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < 4; k++)
+      if (part[k] > m) m = part[k];
+    atomicMax(result_bits, (unsigned long long)__double_as_longlong(m));  // m >= 0: order-preserving
+  }
+}
+
+hipError_t wdpm_launch_max_diff(const double *w, const double *old, const double *dem, const SlabGeom &g,
+                                int row_lo, int row_hi, unsigned long long *result_bits, hipStream_t s) {
+  hipError_t e = hipMemsetAsync(result_bits, 0, sizeof(unsigned long long), s);
+  if (e != hipSuccess) return e;
+  if (row_hi <= row_lo) return hipSuccess;
+  const size_t first = (size_t)row_lo * g.ncp, last = (size_t)row_hi * g.ncp;
+  size_t blocks = (last - first + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(max_diff_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w, old, dem, first, last,
+                     g.miss, row_lo == 0 ? 1 : 0, result_bits);
+  return hipGetLastError();
+}

@@ -1,0 +1,59 @@
+/*
+ * wdpm_stencil.h — the per-neighbour water transfer, shared by every stencil kernel.
+ *
+ * flow_add  : one neighbour step of runoffs()  (reference src/WDPMCL.c:1945-1959), add + subtract
+ * flow_drain: one neighbour step of runoffd()'s non-outlet branch (WDPMCL.c:1988-2000)
+ *
+ * Both are written branch-free (v_cndmask selects) so a wave never diverges; the values computed
+ * are exactly the reference's: same operands, same operation order, fp64, no contraction.
+ * `x * 0.125` is the correctly rounded x/8 — identical to the reference's `x/8.0`.
+ * The reference's min/max macros are `a<b?a:b` / `a>b?a:b` (WDPMCL.c:19-20) and are restated as
+ * such (not fmin/fmax) so NaN and signed-zero behaviour is the same.
+ *
+ * The caller has already established that the neighbour is a valid cell (bigdem > missingvalue,
+ * WDPMCL.c:1944) — or, in the fused kernel, encodes invalid cells as dem = +inf, which makes
+ * ht_diff = -inf or NaN and therefore `ht_diff > 0` false, i.e. no transfer, with no extra test.
+ */
+#ifndef WDPM_STENCIL_H
+#define WDPM_STENCIL_H
+
+#include <hip/hip_runtime.h>
+
+/* neighbour k = 0..7 in the reference's visiting order: rowloc outer -1..+1, colloc inner -1..+1,
+ * centre skipped (WDPMCL.c:1940-1943) */
+__host__ __device__ constexpr int nb_dr(int k) { return (k < 3) ? -1 : (k < 5 ? 0 : 1); }
+__host__ __device__ constexpr int nb_dc(int k) { return (k < 3) ? k - 1 : (k == 3 ? -1 : (k == 4 ? 1 : k - 6)); }
+
+/* `gate` folds the centre test of the sweep loops (WDPMCL.c:1099) into the transfer condition */
+__device__ __forceinline__ void flow_add(const double dem_c, double &w_c, const double dem_n, double &w_n,
+                                         const bool gate = true) {
+  const double en = dem_n + w_n;                 // :1946
+  const double ht = (dem_c + w_c) - en;          // :1945-1946
+  const bool go = gate & (ht > 0);               // :1947
+  const double x = (dem_c > en) ? w_c : ht;      // :1948 selects w_c/8 (:1949) or ht/8 (:1955)
+  double flow = x * 0.125;
+  flow = (flow < w_c) ? flow : w_c;              // :1957 min(flow, w_c)
+  const double wc2 = w_c - flow;                 // :1958
+  const double wn2 = w_n + flow;                 // :1959
+  w_c = go ? wc2 : w_c;
+  w_n = go ? wn2 : w_n;
+}
+
+__device__ __forceinline__ void flow_drain(const double dem_c, double &w_c, const double dem_n, double &w_n,
+                                           const bool gate = true) {
+  const double cwe = dem_c + w_c;                // :1977
+  const double nwe = dem_n + w_n;                // :1978
+  const double ht = cwe - nwe;                   // :1988
+  const bool go = gate & (ht > 0);               // :1989
+  const double alt = ((dem_c - dem_n) + (w_c - w_n)) * 0.125;   // :1995-1996
+  double flow = (dem_c > nwe) ? w_c * 0.125 : alt;              // :1990-1991
+  flow = (flow > 0.0) ? flow : 0.0;              // :1998 max(flow, 0.0)
+  flow = (flow < w_c) ? flow : w_c;              // :1998 min(.., w_c)
+  double wc2 = w_c - flow;
+  wc2 = (wc2 > 0.0) ? wc2 : 0.0;                 // :1999 max(w_c - flow, 0.0)
+  const double wn2 = w_n + flow;                 // :2000
+  w_c = go ? wc2 : w_c;
+  w_n = go ? wn2 : w_n;
+}
+
+#endif
