@@ -1,0 +1,38 @@
+"""Worker for tests/test_rowblock.py: one rank of a row-block-decomposed WDPM run on CPU ranks
+(gloo) with the oracle as the compute back-end behind the same C ABI the GPUs use."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def run(rank, world, port, libpath, case, outdir):
+    import torch.distributed as dist
+    import wdpm_amd
+    from wdpm_amd.rowblock import HostTransport, RowBlockSolver
+    from helpers import pad, random_case
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    lib = wdpm_amd.load(libpath)
+    dem, water, miss = random_case(case["seed"], case["R"], case["C"])
+    bd, bw = pad(dem, water, miss)
+    s = RowBlockSolver(lib, case["module"], case["R"], case["C"], miss, rank=rank, nranks=world,
+                       exchange_every=case["k"], transport=HostTransport(dist), dist=dist,
+                       **case.get("ctx_kw", {}))
+    s.upload_global(bd, bw)
+    mds = [s.run_block(n, case["thres"]) for n in case["blocks"]]
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), own=s.owned_water(), lo=s.slab.own_lo, hi=s.slab.own_hi,
+             mds=np.array(mds))
+    s.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    import json
+    rank, world, port, libpath, case, outdir = sys.argv[1:7]
+    run(int(rank), int(world), int(port), libpath, json.loads(case), outdir)

@@ -1,0 +1,101 @@
+"""Row-block decomposition (wdpm_amd/rowblock.py) on CPU ranks: world size 2 and 3 over gloo with the
+oracle back-end must reproduce the single-slab result bit for bit, for several exchange intervals;
+and the halo-depth rule itself is checked to be tight."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+from conftest import ORACLE_SO, ROOT
+from helpers import bits_equal, n_bit_diff, pad, random_case
+from wdpm_amd.rowblock import RowBlockSolver, halo_depth, partition
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def run_ranks(world, case, libpath=ORACLE_SO, env=None):
+    port = free_port()
+    with tempfile.TemporaryDirectory() as td:
+        procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "rowblock_worker.py"), str(r),
+                                   str(world), str(port), libpath, json.dumps(case), td], env=env)
+                 for r in range(world)]
+        rcs = [p.wait(timeout=600) for p in procs]
+        assert rcs == [0] * world, rcs
+        return [dict(np.load(os.path.join(td, f"rank{r}.npz"))) for r in range(world)]
+
+
+def single(oracle, case):
+    dem, water, miss = random_case(case["seed"], case["R"], case["C"])
+    bd, bw = pad(dem, water, miss)
+    s = RowBlockSolver(oracle, case["module"], case["R"], case["C"], miss)
+    s.upload_global(bd, bw)
+    mds = [s.run_block(n, case["thres"]) for n in case["blocks"]]
+    w = s.ctx.download_water()
+    s.close()
+    return w, mds
+
+
+def test_partition_properties():
+    for nrows, n, k in [(16384, 8, 4), (16384, 8, 1), (16384, 2, 10), (482, 3, 2), (8192, 4, 16), (100, 2, 1)]:
+        slabs = partition(nrows, n, k)
+        up, down = halo_depth(k)
+        assert slabs[0].own_lo == 0 and slabs[-1].own_hi == nrows + 1
+        for a, b in zip(slabs, slabs[1:]):
+            assert b.own_lo == a.own_hi + 1
+            assert b.own_lo % 3 == 2
+        for s in slabs:
+            assert s.row0 % 3 == 0
+            assert s.row0 + s.rows <= nrows + 2
+            if s.rank > 0:
+                assert s.up == up
+            if s.rank < n - 1:
+                assert s.down == min(down, nrows + 1 - s.own_hi)
+    with pytest.raises(ValueError):
+        partition(60, 4, 8)
+
+
+@pytest.mark.parametrize("world,k", [(2, 1), (2, 4), (3, 2)])
+def test_multirank_equals_single_slab(oracle, world, k):
+    case = dict(seed=11, R=150 if world == 2 else 200, C=61, module="add", k=k, thres=0.005 / 1000, blocks=[13, 8])
+    want, mds = single(oracle, case)
+    got = run_ranks(world, case)
+    for g in got:
+        lo, hi = int(g["lo"]), int(g["hi"])
+        assert bits_equal(g["own"], want[lo:hi + 1]), f"rows {lo}..{hi}: {n_bit_diff(g['own'], want[lo:hi + 1])} cells differ"
+        assert list(g["mds"]) == mds
+
+
+def test_halo_depth_is_sufficient(oracle):
+    """k iterations on a slab with halos (3k-1 up, 6k-2 down) leave the owned rows exact; the halo
+    of k-1 iterations does not (the rule is a block-granular bound: within a 3x3 block the top row
+    does not depend on the bottom row, so it is not tight to the last row)."""
+    R, C, k = 120, 40, 2
+    dem, water, miss = random_case(5, R, C, missing_frac=0.0, dry_frac=0.0)
+    bd, bw = pad(dem, water, miss)
+    with oracle.context(module="add", nrows=R, ncols=C, missingvalue=miss) as full:
+        full.upload(bd, bw)
+        full.iterate(k)
+        want = full.download_water()
+    up, down = halo_depth(k)
+    lo, hi = 44, 79                       # owned rows, lo % 3 == 2, hi % 3 == 1
+    def owned_after(u, d):
+        r0, r1 = lo - u, hi + d
+        r0 -= r0 % 3
+        with oracle.context(module="add", nrows=R, ncols=C, missingvalue=miss, slab_row0=r0,
+                            slab_rows=r1 - r0 + 1) as c:
+            c.upload(bd[r0:r1 + 1], bw[r0:r1 + 1])
+            c.iterate(k)
+            return c.download_rows(lo - r0, hi - lo + 1)
+    assert bits_equal(owned_after(up, down), want[lo:hi + 1])
+    up1, _ = halo_depth(k - 1)
+    assert not bits_equal(owned_after(up1, down), want[lo:hi + 1])   # upward bound is tight
+    assert not bits_equal(owned_after(up, 3), want[lo:hi + 1])       # downward one is conservative
