@@ -1,0 +1,115 @@
+"""The WDPMCL drop-in command line (wdpm_amd/csrc/wdpmcl_main.c) against what the unmodified
+reference executable printed and wrote (tests/golden/basin5_cli.json): report text identical except
+the wall-clock column, output and scratch rasters byte-identical, same exit codes.
+
+CPU tests run the product's host code linked against the oracle back-end (oracle/_build/
+WDPMCL_oracle, test-only); the gpu-marked tests run the shipped wdpm_amd/bin/WDPMCL on the HIP path."""
+import gzip
+import hashlib
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+sys.path.insert(0, GOLDEN)
+from make_golden import file_sha, parse_report, strip_timing  # noqa: E402
+
+ORACLE_CLI = os.path.join(ROOT, "oracle", "_build", "WDPMCL_oracle")
+HIP_CLI = os.path.join(ROOT, "wdpm_amd", "bin", "WDPMCL")
+
+
+@pytest.fixture(scope="module")
+def golden():
+    with open(os.path.join(GOLDEN, "basin5_cli.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture()
+def workdir(tmp_path):
+    with gzip.open(os.path.join(GOLDEN, "basin5.asc.gz"), "rb") as f, open(tmp_path / "basin5.asc", "wb") as g:
+        shutil.copyfileobj(f, g)
+    return tmp_path
+
+
+def run(exe, args, cwd):
+    p = subprocess.run([exe] + [str(a) for a in args], cwd=cwd, capture_output=True, text=True, timeout=1500)
+    return p.returncode, p.stdout, p.stderr
+
+
+def check(exe, golden, key, cwd, outfile):
+    g = golden[key]
+    rc, out, err = run(exe, g["args"], cwd)
+    assert rc == g["rc"], err
+    blocks, summary = parse_report(out)
+    assert blocks == g["blocks"]
+    assert summary == g["summary"]
+    assert hashlib.sha256(strip_timing(out).encode()).hexdigest() == g["report_sha256_nontiming"]
+    assert file_sha(os.path.join(cwd, outfile)) == g["out_sha256"]
+    return err
+
+
+def chain(exe, golden, cwd):
+    """validation/validate_WDPM.sh: add 10 mm -> drain -> subtract 10 mm, then water-file + scratch path"""
+    check(exe, golden, "val_add10", cwd, "a10.asc")
+    check(exe, golden, "val_drain", cwd, "a10d.asc")
+    check(exe, golden, "val_sub10", cwd, "a10s.asc")
+    check(exe, golden, "add20_on_a10_scratch", cwd, "a30.asc")
+    assert file_sha(os.path.join(cwd, "scr.asc")) == golden["add20_on_a10_scratch"]["scratch_sha256"]
+
+
+def usage(exe, golden, cwd):
+    for key in ("usage_none", "usage_add", "usage_badargc"):
+        rc, out, _ = run(exe, golden[key]["args"], cwd)
+        assert rc == 42 and out == golden[key]["stdout"]
+    # drain without a water file: message + exit 42 (WDPMCL.c:983-988)
+    rc, out, _ = run(exe, ["drain", "basin5.asc", "nope.asc", "o.asc", "NULL", 0.1, 1.0, 0, 0, 0.005, 0], cwd)
+    assert rc == 42 and "Error water file missing" in out
+    # add needs 13 arguments, subtract 12: the other count prints the usage after the banner
+    rc, out, _ = run(exe, ["subtract", "basin5.asc", "NULL", "o.asc", "NULL", 10, 1.0, 1.0, 0, 0, 0.005, 0], cwd)
+    assert rc == 42 and "Subtract module specified" in out and "Wetland DEM Ponding Model" in out
+
+
+def param_file(exe, golden, cwd):
+    g = golden["cfg2_add300_k1000"]
+    with open(os.path.join(cwd, "params.txt"), "w") as f:
+        f.write("\n".join(g["args"]) + "\n")
+    rc, out, err = run(exe, ["params.txt"], cwd)
+    assert rc == 0, err
+    assert parse_report(out)[0] == g["blocks"]
+    assert file_sha(os.path.join(cwd, "a300.asc")) == g["out_sha256"]
+
+
+def test_cli_usage_and_exit_codes(workdir, golden):
+    usage(ORACLE_CLI, golden, workdir)
+
+
+def test_cli_validation_chain_on_oracle_backend(workdir, golden):
+    chain(ORACLE_CLI, golden, workdir)
+
+
+def test_cli_parameter_file(workdir, golden):
+    param_file(ORACLE_CLI, golden, workdir)
+
+
+@pytest.mark.gpu
+def test_hip_cli_usage(workdir, golden):
+    usage(HIP_CLI, golden, workdir)
+
+
+@pytest.mark.gpu
+def test_hip_cli_validation_chain(workdir, golden):
+    """the reference's own end-to-end known answers (0.420810 m patch, 97577.54 / 86762.40 m3), via
+    byte-identical rasters, on the HIP path"""
+    chain(HIP_CLI, golden, workdir)
+
+
+@pytest.mark.gpu
+def test_hip_cli_baseline_configs(workdir, golden):
+    err = check(HIP_CLI, golden, "cfg1_add100_k3000", workdir, "a100.asc")
+    assert "hip-gfx950" in err
+    param_file(HIP_CLI, golden, workdir)

@@ -1,0 +1,585 @@
+/*
+ * wdpmcl_main.c — the WDPMCL command line on top of the wdpm C ABI (include/wdpm.h).
+ *
+ * Drop-in for the reference executable (src/WDPMCL.c main(), :266-1506): same positional
+ * arguments (argc 13 for add, 12 for subtract/drain, or one parameter-file argument), same units,
+ * "NULL" handling, report text on stdout, ArcASCII water/scratch/output files and exit codes
+ * (42 for usage errors and for a missing drain water file).  The redistribution loop itself —
+ * flush, snapshot, 1000 iterations of the 9-colour sweep, max-change test — runs on the GPU through
+ * wdpm_run_block(); this file is host plumbing written in C like the reference's.
+ *
+ * Differences, all deliberate:
+ *   - the "0 serial / 1 OpenCL" and "0 CPU / 1 GPU" slots are accepted and echoed in the report as
+ *     the reference does, but the computation always runs on the HIP device (there is no CPU
+ *     path in this build); the device in use is reported on stderr so stdout stays identical.
+ *   - runoff.cl is not needed in the working directory.
+ *   - malformed invocations that make the reference read uninitialised memory (unknown module with
+ *     12/13 arguments, short parameter file) print the usage text and exit 42 instead.
+ *   - WDPM_DEVICE=<n> selects the HIP device (default 0).
+ */
+#include <ctype.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <sys/time.h>
+
+#include "../../include/wdpm.h"
+#include "arcascii.h"
+
+#define ITER_PER_BLOCK 1000 /* IterationNum, WDPMCL.c:597 */
+
+typedef struct {
+  int module;               /* WDPM_ADD / WDPM_SUBTRACT / WDPM_DRAIN */
+  char name[20];            /* module as typed */
+  char dem[512], water[512], output[512], scratch[512];
+  double addwater, subtractwater, rof, eltol, draintol, thres; /* as typed (mm, m3) */
+  int cpu, gpu, iteration_limit;
+} run_config;
+
+static void put_lines(const char *const *lines) {
+  for (; *lines; lines++) printf("%s\n", *lines);
+}
+
+/* ---- usage texts (WDPMCL.c:1658-1745) ------------------------------------------------------ */
+static void usage_module(const char *module) {
+  const int is_add = strcmp(module, "add") == 0, is_sub = strcmp(module, "subtract") == 0,
+            is_drain = strcmp(module, "drain") == 0;
+  printf("%s\n", "                                          ");
+  printf("%s\n", "Program arguments in order of specification");
+  if (is_add) printf("%s\n", "Add module specified");
+  else if (is_sub) printf("%s\n", "Subtract module specified");
+  else if (is_drain) printf("%s\n", "Drain module specified");
+  printf("%s\n", "DEM file name (string) ");
+  printf("%s\n", is_add ? "Water file name (string) - Optional, Use NULL to omit" : "Water file name (string)");
+  printf("%s\n", "Output file name (string)");
+  printf("%s\n", "Scratch file name (string) - Optional, use NULL to omit");
+  if (is_add) {
+    printf("%s\n", "Depth of water to add (mm) (real)");
+    printf("%s\n", "Water runoff fraction (real)");
+    printf("%s\n", "Elevation tolerance (mm) (real)");
+  } else if (is_sub) {
+    printf("%s\n", "Depth of water to remove (mm) (real)");
+    printf("%s\n", "Elevation tolerance (mm) (real)");
+  } else if (is_drain) {
+    printf("%s\n", "Elevation tolerance (mm) (real)");
+    printf("%s\n", "Drain tolerance (m3) (real)");
+  }
+  printf("%s\n", "Specify 0 for serial CPU and 1 for opencl ");
+  printf("%s\n", "Specify 0 for OpenCL CPU and 1 for opencl GPU ");
+  printf("%s\n", "Zero depth threshold (mm) (real)");
+  printf("%s\n", "Maximum number of iterations (integer) - Optional, Use 0 to omit ");
+  printf("%s\n", "                                          ");
+}
+
+static void usage_all(void) {
+  static const char *const text[] = {
+      "Module name: add",
+      "DEM file name (string)",
+      "Water file name (string) - Optional, use --NULL-- to omit",
+      "Output file name (string)",
+      "Scratch file name (string) - Optional, use --NULL-- to omit",
+      "Depth of water to add (mm) (real)",
+      "Water runoff fraction (real)",
+      "Elevation tolerance (mm) (real)",
+      "Specify 0 for serial CPU and 1 for opencl ",
+      "Specify 0 for OpenCL CPU and 1 for opencl GPU ",
+      "Zero depth threshold (mm) (real) ",
+      "Maximum number of iterations (integer) - Optional, Use 0 to omit",
+      "                                          ",
+      "                                          ",
+      "Module name: subtract",
+      "Path and Name of Report file",
+      "DEM file name (string)",
+      "Water file name (string)",
+      "Output file name (string)",
+      "Scratch file name (string) - Optional, use --NULL-- to omit",
+      "Depth of water to remove (mm) (real)",
+      "Elevation tolerance (mm) (real)",
+      "Specify 0 for serial CPU and 1 for opencl ",
+      "Specify 0 for OpenCL CPU and 1 for opencl GPU ",
+      "Zero depth threshold (mm) (real) ",
+      "Maximum number of iterations (integer) - Optional, Use 0 to omit ",
+      "                                          ",
+      "                                          ",
+      "Module name: drain",
+      "Path and Name of Report file",
+      "DEM file name (string)",
+      "Water file name (string) ",
+      "Output file name (string)",
+      "Scratch file name (string) - Optional, use --NULL-- to omit",
+      "Elevation tolerance (mm) (real)",
+      "Drain tolerance (m3) (real)",
+      "Specify 0 for serial CPU and 1 for opencl ",
+      "Specify 0 for OpenCL CPU and 1 for opencl GPU ",
+      "Zero depth threshold (mm) (real) ",
+      "Maximum number of iterations (integer) - Optional, Use 0 to omit",
+      "                                          ",
+      NULL};
+  put_lines(text);
+}
+
+/* ---- banner (WDPMCL.c:1616-1655) ---------------------------------------------------------- */
+static void banner(int module) {
+  static const char blank[] = "                                                                   ";
+  static const char *const head[] = {
+      blank, blank,
+      "Wetland DEM Ponding Model version 2.0",
+      "Copyright (c) 2010, 2012, 2014, 2020 Kevin Shook, Centre for Hydrology",
+      "Developed by Oluwaseun Sharomi, Raymond Spiteri and Tonghe Liu",
+      "Numerical Simulation Laboratory, University of Saskatchewan.\n",
+      "--------------------------------------------------------------------",
+      blank,
+      "This program is free software: you can redistribute it and/or modify",
+      "it under the terms of the GNU General Public License as published by",
+      "the Free Software Foundation, either version 3 of the License, or",
+      "(at your option) any later version.",
+      blank,
+      "This program is distributed in the hope that it will be useful,",
+      "but WITHOUT ANY WARRANTY; without even the implied warranty of",
+      "MERCHANTABILITY or FITNESS FOR A PARTICULAR PURPOSE.  See the",
+      "GNU General Public License for more details.",
+      blank,
+      "You should have received a copy of the GNU General Public License",
+      "along with this program.  If not, see <http://www.gnu.org/licenses/>.",
+      blank, NULL};
+  put_lines(head);
+  if (module == WDPM_ADD) {
+    printf("%s\n", "This program adds water to an ArcGIS ASCII file of water runoff");
+    printf("%s\n", "and redistributes water over the DEM");
+  } else if (module == WDPM_SUBTRACT) {
+    printf("%s\n", "This program removes a depth water to an ArcGIS ASCII file of water depths");
+    printf("%s\n", "and redistributes water over the DEM");
+  } else if (module == WDPM_DRAIN) {
+    printf("%s\n", "This program drains an ArcGIS ASCII file of water runoff");
+    printf("%s\n", "from the lowest point in the DEM, which acts as a drain");
+  }
+  printf("%s\n", "From the algorithm of Shapiro, M., & Westervelt, J. (1992). ");
+  printf("%s\n", "An Algebra for GIS and Image Processing (pp. 1-22).");
+  printf("%s\n%s\n", blank, blank);
+}
+
+/* ---- parameter echo (WDPMCL.c:1748-1797) --------------------------------------------------- */
+static void echo_parameters(const run_config *c) {
+  printf("%30s\n", "WDPM Parameters");
+  printf("%30s %s\n", "Function used:", c->name);
+  printf("%30s %s\n", "DEM file:", c->dem);
+  printf("%30s %s\n", "Water file:", c->water);
+  printf("%30s %s\n", "Output file:", c->output);
+  printf("%30s %s\n", "Scratch file:", c->scratch);
+  if (c->module == WDPM_ADD) {
+    printf("%30s %0.4f %s\n", "Water added:", c->addwater, "mm");
+    printf("%30s %0.4f\n", "Runoff fraction:", c->rof);
+    printf("%30s %0.4f %s\n", "Elevation tolerance:", c->eltol, "mm");
+  } else if (c->module == WDPM_SUBTRACT) {
+    printf("%30s %0.4f %s\n", "Water subtracted:", c->subtractwater, "mm");
+    printf("%30s %0.4f %s\n", "Elevation tolerance:", c->eltol, "mm");
+  } else {
+    printf("%30s %0.4f %s\n", "Elevation tolerance:", c->eltol, "mm");
+    printf("%30s %0.4f %s\n", "Drain tolerance:", c->draintol, "m3");
+  }
+  printf("%30s %0.4f %s\n", "Zero depth threshold:", c->thres, "mm");
+  if (c->iteration_limit == 0) printf("%30s\n", "No iteration limitation is set");
+  else printf("%30s %d\n", "Maximum number of iterations:", c->iteration_limit);
+  printf("%s\n", "               ");
+  if (c->cpu == 0) {
+    printf("%41s\n", "Using Serial CPU for Computation");
+  } else {
+    printf("%41s\n", "Using Parallel OpenCL for Computation");
+    if (c->gpu == 0) printf("%40s\n", "Using OpenCL CPU for Computation");
+    if (c->gpu == 1) printf("%40s\n", "Using OpenCL GPU for Computation");
+  }
+}
+
+static void iteration_headings(int module) {
+  printf("%s\n", "               ");
+  printf("%30s\n", "Doing calculations");
+  if (module == WDPM_DRAIN) {
+    printf("%15s %15s %15s %15s %15s\n", "iterations", "max diff", "vol change", "water left", "run time");
+    printf("%13s %14s %15s %16s %17s\n", " ", "(m)", "(m3)", "(m3)", "(s)");
+  } else {
+    printf("%15s %15s %15s\n", "iterations", "max diff", "run time");
+    printf("%13s %14s %15s\n", " ", "(m)", "(s)");
+  }
+}
+
+/* ---- small helpers -------------------------------------------------------------------------- */
+static int is_null_name(const char *s) { /* "NULL" in any case, WDPMCL.c:666-668 via upcase() */
+  return strlen(s) == 4 && toupper((unsigned char)s[0]) == 'N' && toupper((unsigned char)s[1]) == 'U' &&
+         toupper((unsigned char)s[2]) == 'L' && toupper((unsigned char)s[3]) == 'L';
+}
+
+static int file_exists(const char *path) {
+  struct stat st;
+  return stat(path, &st) == 0;
+}
+
+static double seconds_since(const struct timeval *t0) {
+  struct timeval t;
+  gettimeofday(&t, NULL);
+  return (double)(t.tv_usec - t0->tv_usec) / 1000000 + (double)(t.tv_sec - t0->tv_sec);
+}
+
+static void die_usage(const char *module) {
+  usage_module(module);
+  exit(42);
+}
+
+static int module_from_name(const char *s) {
+  if (strcmp(s, "add") == 0) return WDPM_ADD;
+  if (strcmp(s, "subtract") == 0) return WDPM_SUBTRACT;
+  if (strcmp(s, "drain") == 0) return WDPM_DRAIN;
+  return -1;
+}
+
+/* positional values after the module name, in the order of WDPMCL.c:386-398 / :445-456 / :501-512 */
+static void assign_fields(run_config *c, char **v) {
+  snprintf(c->dem, sizeof c->dem, "%s", v[0]);
+  snprintf(c->water, sizeof c->water, "%s", v[1]);
+  snprintf(c->output, sizeof c->output, "%s", v[2]);
+  snprintf(c->scratch, sizeof c->scratch, "%s", v[3]);
+  int k = 4;
+  if (c->module == WDPM_ADD) {
+    c->addwater = atof(v[k++]);
+    c->rof = atof(v[k++]);
+    c->eltol = atof(v[k++]);
+  } else if (c->module == WDPM_SUBTRACT) {
+    c->subtractwater = atof(v[k++]);
+    c->eltol = atof(v[k++]);
+  } else {
+    c->eltol = atof(v[k++]);
+    c->draintol = atof(v[k++]);
+  }
+  c->cpu = (int)atof(v[k++]);
+  c->gpu = (int)atof(v[k++]);
+  c->thres = atof(v[k++]);
+  c->iteration_limit = (int)atof(v[k++]);
+}
+
+/* whitespace-separated tokens of a parameter file (WDPMCL.c:334-343,366-385) */
+static int read_param_file(const char *path, char tok[16][512]) {
+  FILE *f = fopen(path, "r");
+  if (!f) return -1;
+  int n = 0;
+  while (n < 16 && fscanf(f, "%511s", tok[n]) == 1) n++;
+  fclose(f);
+  return n;
+}
+
+static void parse_command_line(int argc, char **argv, run_config *c) {
+  memset(c, 0, sizeof *c);
+  if (argc == 1) { usage_all(); exit(42); }
+  static char tok[16][512];
+  char *vals[16];
+  int nvals = 0, from_file = 0;
+  if (argc == 2) {
+    if (module_from_name(argv[1]) >= 0) die_usage(argv[1]);
+    int n = read_param_file(argv[1], tok);
+    if (n < 1) { usage_all(); exit(42); }
+    snprintf(c->name, sizeof c->name, "%.19s", tok[0]);
+    for (int i = 1; i < n; i++) vals[nvals++] = tok[i];
+    from_file = 1;
+  } else {
+    snprintf(c->name, sizeof c->name, "%.19s", argv[1]);
+    if (argc != 12 && argc != 13) die_usage(c->name);
+    for (int i = 2; i < argc; i++) vals[nvals++] = argv[i];
+  }
+  c->module = module_from_name(c->name);
+  banner(c->module);
+  const int need = c->module == WDPM_ADD ? 11 : 10;
+  if (c->module < 0 || (from_file ? nvals < need : nvals != need)) die_usage(c->name);
+  assign_fields(c, vals);
+}
+
+/* ---- module set-up (WDPMCL.c:643-1034) ------------------------------------------------------ */
+typedef struct {
+  int R, C;
+  double missing, cellsize, cellarea;
+  double *dem, *water;          /* R x C */
+  double *bigdem, *bigwater;    /* (R+2) x (C+2) */
+  double initial_vol, basin_area, totaldrain0;
+  int basincount, drainrow, draincol;
+} raster_state;
+
+static double volume_where(const raster_state *s, double dem_above) {
+  double v = 0;
+  const size_t n = (size_t)s->R * s->C;
+  for (size_t i = 0; i < n; i++)
+    if (s->dem[i] > dem_above) v += s->water[i];
+  return v * s->cellarea;
+}
+
+static void zero_water(raster_state *s, int valid_only) {
+  const size_t n = (size_t)s->R * s->C;
+  for (size_t i = 0; i < n; i++)
+    if (!valid_only || s->dem[i] > s->missing) s->water[i] = 0;
+}
+
+/* water-file branch shared by add and subtract: returns 1 when an existing file was read */
+static int load_or_create_water(const run_config *c, raster_state *s) {
+  if (!is_null_name(c->water)) {
+    if (file_exists(c->water)) {
+      printf("%30s\n", "Existing water file found");
+      asc_read_grid(c->water, s->R, s->C, s->water);
+      return 1;
+    }
+    printf("%30s\n", "Water file missing, will be created");
+  } else {
+    printf("%30s\n", "Water file will be created");
+  }
+  zero_water(s, c->module == WDPM_ADD);
+  return 0;
+}
+
+static void apply_module_water(const run_config *c, raster_state *s) {
+  const size_t n = (size_t)s->R * s->C;
+  if (c->module == WDPM_ADD) {
+    const double add = c->addwater / 1000.0, rof = c->rof;          /* WDPMCL.c:419 */
+    for (size_t i = 0; i < n; i++)                                   /* :727-733 */
+      if (s->dem[i] > s->missing && s->water[i] > 0) s->water[i] += add;
+    for (size_t i = 0; i < n; i++)                                   /* :734-740 */
+      if (s->dem[i] > s->missing && s->water[i] <= 0) s->water[i] = add * rof;
+  } else if (c->module == WDPM_SUBTRACT) {
+    const double sub = c->subtractwater / 1000;                      /* :475 */
+    for (size_t i = 0; i < n; i++)                                   /* :879-885 */
+      if (s->dem[i] > s->missing) {
+        const double d = s->water[i] - sub;
+        s->water[i] = d > 0 ? d : 0;
+      }
+  }
+}
+
+static void announce_no_scratch(int module) {
+  printf("%s\n", "           ");
+  printf("%30s\n", "No Scratch file found");
+  printf("%s\n", "           ");
+  printf("%30s\n", module == WDPM_SUBTRACT ? "New Scratch will be saved." : "New Scratch will be saved");
+  printf("%s\n", "           ");
+  printf("%30s\n", "Now proceeding with Waterfile checking");
+  printf("%s\n", "           ");
+}
+
+static void setup_module(const run_config *c, raster_state *s) {
+  const int have_scratch_name = !is_null_name(c->scratch);
+  int resumed = 0;
+  if (c->module == WDPM_ADD) s->initial_vol = volume_where(s, s->missing);      /* :656-664 (water is 0) */
+  if (c->module == WDPM_SUBTRACT) s->initial_vol = volume_where(s, 0.0);        /* :813-821 (dem > 0) */
+  if (have_scratch_name) {
+    if (file_exists(c->scratch)) {                                             /* resume, :668-673 */
+      printf("%s\n", "           ");
+      printf("%30s\n", "Scratch file found");
+      asc_read_grid(c->scratch, s->R, s->C, s->water);
+      resumed = 1;
+    } else {
+      announce_no_scratch(c->module);
+    }
+  }
+  if (!resumed) {
+    if (c->module == WDPM_DRAIN) {
+      if (!file_exists(c->water)) {                                            /* :968-973, :983-988 */
+        printf("%30s\n", "Error water file missing");
+        exit(42);
+      }
+      printf("%30s\n", "Existing water file found");
+      asc_read_grid(c->water, s->R, s->C, s->water);
+    } else {
+      const int read_file = load_or_create_water(c, s);
+      /* the reference recomputes the initial volume only on the scratch-name branch (:690-699, :846-855) */
+      if (read_file && have_scratch_name)
+        s->initial_vol = volume_where(s, c->module == WDPM_ADD ? s->missing : 0.0);
+      apply_module_water(c, s);
+    }
+  }
+  /* padded arrays, WDPMCL.c:796-807 */
+  const int n = s->C + 2;
+  for (size_t i = 0; i < (size_t)(s->R + 2) * n; i++) { s->bigdem[i] = s->missing; s->bigwater[i] = 0; }
+  for (int i = 0; i < s->R; i++)
+    for (int j = 0; j < s->C; j++) {
+      s->bigdem[(size_t)(i + 1) * n + j + 1] = s->dem[(size_t)i * s->C + j];
+      s->bigwater[(size_t)(i + 1) * n + j + 1] = s->water[(size_t)i * s->C + j];
+    }
+  if (c->module == WDPM_DRAIN) {
+    double mindrain = 100000000;                                               /* :1005-1017 */
+    for (int i = 0; i < s->R + 2; i++)
+      for (int j = 0; j < n; j++) {
+        const double d = s->bigdem[(size_t)i * n + j];
+        if (d > 0 && d < mindrain) { mindrain = d; s->drainrow = i; s->draincol = j; }
+      }
+    s->initial_vol = volume_where(s, s->missing);                              /* :1019-1028 */
+    const double wd = s->bigwater[(size_t)s->drainrow * n + s->draincol];
+    s->totaldrain0 = wd > 0 ? wd : 0;                                          /* :1029 */
+    s->basin_area = s->basincount * s->cellarea;
+    printf("%s\n", "               ");                                         /* :1820-1828 */
+    printf("%30s\n", "Basin summary");
+    printf("%20s %10.4f %s\n", "Basin area:", s->basin_area, "m2");
+    printf("%20s %10.4f %s\n", "Initial volume:", s->initial_vol, "m3");
+    printf("%20s %d\n", "Drain column:", s->draincol);
+    printf("%20s %d\n", "Drain row:", s->drainrow);
+    printf("%20s %10.4f %s\n", "Min DEM elevation:", s->bigdem[(size_t)s->drainrow * n + s->draincol], "m");
+  }
+  iteration_headings(c->module);
+}
+
+static void unpad_water(raster_state *s, int mask_missing) {
+  const int n = s->C + 2;
+  for (int i = 0; i < s->R; i++)
+    for (int j = 0; j < s->C; j++) {
+      const size_t k = (size_t)i * s->C + j;
+      s->water[k] = s->bigwater[(size_t)(i + 1) * n + j + 1];
+      if (mask_missing && s->dem[k] <= s->missing) s->water[k] = s->missing;
+    }
+}
+
+#define ABI_TRY(call)                                                      \
+  do {                                                                     \
+    if ((call) != 0) {                                                     \
+      fprintf(stderr, "WDPMCL: %s: %s\n", #call, wdpm_last_error());       \
+      exit(1);                                                             \
+    }                                                                      \
+  } while (0)
+
+int main(int argc, char **argv) {
+  setbuf(stdout, NULL);
+  run_config cfg;
+  parse_command_line(argc, argv, &cfg);
+  echo_parameters(&cfg);
+
+  asc_header hdr;
+  if (asc_read_header(cfg.dem, &hdr) != 0) {
+    fprintf(stderr, "WDPMCL: cannot read DEM file %s\n", cfg.dem);
+    return 1;
+  }
+  printf("%s\n", "                  ");                                         /* WDPMCL.c:1602-1613 */
+  printf("%30s\n", "ArcGIS file header");
+  printf("%30s %d\n", hdr.name[0], (int)hdr.value[0]);
+  printf("%30s %d\n", hdr.name[1], (int)hdr.value[1]);
+  printf("%30s %9.1f\n", hdr.name[2], hdr.value[2]);
+  printf("%30s %9.1f\n", hdr.name[3], hdr.value[3]);
+  printf("%30s %9.1f\n", hdr.name[4], hdr.value[4]);
+  printf("%30s %9.1f\n", hdr.name[5], hdr.value[5]);
+
+  raster_state st;
+  memset(&st, 0, sizeof st);
+  st.C = (int)hdr.value[0];
+  st.R = (int)hdr.value[1];
+  st.missing = hdr.value[5];
+  st.cellsize = hdr.value[4];
+  st.cellarea = st.cellsize * st.cellsize;
+  if (st.R < 1 || st.C < 1) {
+    fprintf(stderr, "WDPMCL: bad raster size in %s\n", cfg.dem);
+    return 1;
+  }
+  printf("%30s\n", "Setting array sizes");
+  const size_t ncell = (size_t)st.R * st.C, nbig = (size_t)(st.R + 2) * (st.C + 2);
+  st.dem = (double *)calloc(ncell, sizeof(double));
+  st.water = (double *)calloc(ncell, sizeof(double));
+  st.bigdem = (double *)calloc(nbig, sizeof(double));
+  st.bigwater = (double *)calloc(nbig, sizeof(double));
+  if (!st.dem || !st.water || !st.bigdem || !st.bigwater) {
+    fprintf(stderr, "WDPMCL: out of memory\n");
+    return 1;
+  }
+  asc_read_grid(cfg.dem, st.R, st.C, st.dem);
+  printf("%s\n", "           ");
+  printf("%s\n", "           ");
+  for (size_t i = 0; i < ncell; i++)
+    if (st.dem[i] > st.missing) st.basincount++;                               /* :643-650 */
+
+  setup_module(&cfg, &st);
+
+  /* unit conversions, WDPMCL.c:417-420 / :473-476 / :528-530 */
+  const double eltol = cfg.eltol / 1000.0;
+  const double thres = cfg.thres / 1000;
+  const double draintol = cfg.draintol;
+
+  wdpm_params p;
+  memset(&p, 0, sizeof p);
+  p.module = cfg.module;
+  p.nrows = st.R;
+  p.ncols = st.C;
+  p.drainrow = st.drainrow;
+  p.draincol = st.draincol;
+  p.missingvalue = st.missing;
+  p.device = getenv("WDPM_DEVICE") ? atoi(getenv("WDPM_DEVICE")) : 0;
+  wdpm_ctx *ctx = NULL;
+  ABI_TRY(wdpm_create(&ctx, &p));
+  fprintf(stderr, "WDPMCL: redistribution loop on back-end %s, device %d\n", wdpm_backend_name(), p.device);
+  ABI_TRY(wdpm_upload(ctx, st.bigdem, st.bigwater));
+  if (cfg.module == WDPM_DRAIN) ABI_TRY(wdpm_set_totaldrain(ctx, st.totaldrain0));
+
+  /* block loop, WDPMCL.c:1049-1377 */
+  struct timeval t0;
+  gettimeofday(&t0, NULL);
+  const int write_scratch = !is_null_name(cfg.scratch);
+  int k = 0, done = 0;
+  while (!done) {
+    double max_diff = 0, diffdrain = 0, final_vol = 0;
+    ABI_TRY(wdpm_run_block(ctx, ITER_PER_BLOCK, thres, &max_diff));
+    k += ITER_PER_BLOCK;
+    if (cfg.module == WDPM_DRAIN) {
+      double final_sum = 0;
+      ABI_TRY(wdpm_drain_stats(ctx, &diffdrain, &final_sum));
+      diffdrain *= st.cellarea;                                                /* :1258 */
+      final_vol = final_sum * st.cellarea;                                     /* :1267 */
+      printf("%7s %d %7s %8.3f %5s %10.1f %5s %12.1f %5s %8.2f\n", "", k, "", max_diff, "", diffdrain, "",
+             final_vol, "", seconds_since(&t0));
+    } else {
+      printf("%7s %d %7s %8.3f %5s %8.2f\n", "", k, "", max_diff, "", seconds_since(&t0));
+    }
+    done = max_diff <= eltol;                                                  /* :1324,1350 */
+    if (cfg.module == WDPM_DRAIN && diffdrain < draintol) done = 1;            /* :1287,1303 */
+    if (cfg.iteration_limit > 0 && k >= cfg.iteration_limit) done = 1;
+    if (!done && write_scratch) {                                              /* checkpoint, :1290-1372 */
+      ABI_TRY(wdpm_download_water(ctx, st.bigwater));
+      unpad_water(&st, cfg.module == WDPM_ADD);
+      asc_write_grid(cfg.scratch, &hdr, st.R, st.C, st.water);
+    }
+  }
+
+  double totaldrain = 0;
+  ABI_TRY(wdpm_download_water(ctx, st.bigwater));
+  if (cfg.module == WDPM_DRAIN) ABI_TRY(wdpm_get_totaldrain(ctx, &totaldrain));
+  wdpm_destroy(ctx);
+
+  /* final statistics, WDPMCL.c:1379-1467 */
+  unpad_water(&st, 1);
+  int watercount = 0;
+  double watertotal = 0, final_vol = 0;
+  for (size_t i = 0; i < ncell; i++) {
+    if (st.water[i] > 0.001 && st.dem[i] > st.missing) watercount++;
+    if (st.dem[i] > st.missing) watertotal += st.water[i];
+  }
+  final_vol = watertotal * st.cellarea;
+  const double meanwater = watertotal / ((float)watercount);
+  const double waterfrac = (float)watercount / (float)st.basincount;
+  double drainvol = 0, draindepth = 0;
+  if (cfg.module == WDPM_DRAIN) {
+    drainvol = totaldrain * st.cellarea;
+    draindepth = (drainvol / ((float)st.basincount * st.cellarea)) * 1000;
+  }
+  double maxdepth = st.water[0];
+  for (size_t i = 0; i < ncell; i++)
+    if (st.water[i] > maxdepth) maxdepth = st.water[i];
+  maxdepth = maxdepth * 1000;
+
+  printf("%s\n", "                     ");                                      /* :1832-1857 */
+  printf("%30s\n", "WDPM run summary");
+  printf("%20s %10.2f %s\n", "Initial volume", st.initial_vol, "m3");
+  printf("%20s %10.2f %s\n", "Final volume", final_vol, "m3");
+  if (cfg.module == WDPM_DRAIN) {
+    printf("%20s %10.2f %s\n", "Volume change", st.initial_vol - final_vol, "m3");
+    printf("%20s %10.2f %s\n", "Volume drained", drainvol, "m3");
+  } else {
+    printf("%20s %10.2f %s\n", "Volume change", final_vol - st.initial_vol, "m3");
+  }
+  printf("%20s %10.4f %s\n", "Final water coverage", waterfrac, "");
+  printf("%20s %10.2f %s\n", "Mean water depth", meanwater * 1000., "mm");
+  if (cfg.module == WDPM_DRAIN) printf("%20s %10.2f %s\n", "Depth drained", draindepth, "mm ");
+  printf("%20s %10.2f %s\n", "Max water depth", maxdepth, "mm ");
+
+  asc_write_grid(cfg.output, &hdr, st.R, st.C, st.water);
+  printf("%20s %10.2f %s\n", "Run Time", seconds_since(&t0), "s");
+  free(st.dem); free(st.water); free(st.bigdem); free(st.bigwater);
+  return 0;
+}
