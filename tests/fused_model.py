@@ -99,7 +99,7 @@ def stage(W, D, s0):
         W[r][0], W[r][1], W[r][2] = w[k]
     # oj = 2: own 1,2 + next lane's column 0
     wx0 = [lane_next(W[r][0], 0.0) for r in rows]
-    dx0 = [lane_next(D[r][0], INF) for r in rows]
+    dx0 = [lane_next(D[r][0], 0.0) for r in rows]
     w = [[W[r][1], W[r][2], wx0[k]] for k, r in enumerate(rows)]
     d = [[D[r][1], D[r][2], dx0[k]] for k, r in enumerate(rows)]
     block_update(w, d)
@@ -107,7 +107,7 @@ def stage(W, D, s0):
         W[r][1], W[r][2], wx0[k] = w[k]
     # oj = 3: own 2 + next lane's columns 0,1
     wx1 = [lane_next(W[r][1], 0.0) for r in rows]
-    dx1 = [lane_next(D[r][1], INF) for r in rows]
+    dx1 = [lane_next(D[r][1], 0.0) for r in rows]
     w = [[W[r][2], wx0[k], wx1[k]] for k, r in enumerate(rows)]
     d = [[D[r][2], dx0[k], dx1[k]] for k, r in enumerate(rows)]
     block_update(w, d)

@@ -18,7 +18,8 @@ MODULES = {"add": ADD, "subtract": SUBTRACT, "drain": DRAIN}
 KERNEL_AUTO, KERNEL_PASS, KERNEL_FUSED = 0, 1, 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-HIP_LIB_PATH = os.path.join(_HERE, "csrc", "libwdpm_hip.so")
+# WDPM_HIP_LIB lets a tuning run point at an alternative build of the same HIP library
+HIP_LIB_PATH = os.environ.get("WDPM_HIP_LIB") or os.path.join(_HERE, "csrc", "libwdpm_hip.so")
 
 
 class Params(C.Structure):

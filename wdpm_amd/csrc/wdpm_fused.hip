@@ -41,11 +41,14 @@ constexpr int kStripOut = kStripIn - kHaloL - kHaloR;    // 168 columns stored p
 
 #define WDPM_INF (__builtin_inf())
 
-/* value held by lane+1; lane 63 receives `fill`.  v_mov_b32_dpp wave_shl:1 */
-__device__ __forceinline__ double lane_next(const double v, const double fill) {
+/* value held by lane+1; lane 63 receives 0.0 (DPP bound_ctrl zero fill, so no register has to
+ * be preset).  v_mov_b32_dpp wave_shl:1.  Lane 63's borrowed columns lie beyond the strip: its
+ * blocks of passes oj=2,3 are inside the 16-column right halo whose results are never stored, so
+ * any finite fill is as good as the true value there. */
+__device__ __forceinline__ double lane_next(const double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(__double2loint(fill), lo, 0x130, 0xF, 0xF, false);
-  hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), hi, 0x130, 0xF, 0xF, false);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
 
@@ -131,16 +134,16 @@ __device__ __forceinline__ void stage(double (&W)[7][3], const double (&D)[7][3]
                        D[a][0], D[a][1], D[a][2], D[b][0], D[b][1], D[b][2], D[c][0], D[c][1], D[c][2],
                        rd0, rd1, rd2, cdr[0], cdr[1], cdr[2], ds);
   // oj = 2: own columns 1,2 + column 0 of the next lane
-  double wa0 = lane_next(W[a][0], 0.0), wb0 = lane_next(W[b][0], 0.0), wc0 = lane_next(W[c][0], 0.0);
-  const double da0 = lane_next(D[a][0], WDPM_INF), db0 = lane_next(D[b][0], WDPM_INF),
-               dc0 = lane_next(D[c][0], WDPM_INF);
+  double wa0 = lane_next(W[a][0]), wb0 = lane_next(W[b][0]), wc0 = lane_next(W[c][0]);
+  const double da0 = lane_next(D[a][0]), db0 = lane_next(D[b][0]),
+               dc0 = lane_next(D[c][0]);
   block_update<MODULE>(W[a][1], W[a][2], wa0, W[b][1], W[b][2], wb0, W[c][1], W[c][2], wc0,
                        D[a][1], D[a][2], da0, D[b][1], D[b][2], db0, D[c][1], D[c][2], dc0,
                        rd0, rd1, rd2, cdr[1], cdr[2], cdr[3], ds);
   // oj = 3: own column 2 + columns 0,1 of the next lane
-  double wa1 = lane_next(W[a][1], 0.0), wb1 = lane_next(W[b][1], 0.0), wc1 = lane_next(W[c][1], 0.0);
-  const double da1 = lane_next(D[a][1], WDPM_INF), db1 = lane_next(D[b][1], WDPM_INF),
-               dc1 = lane_next(D[c][1], WDPM_INF);
+  double wa1 = lane_next(W[a][1]), wb1 = lane_next(W[b][1]), wc1 = lane_next(W[c][1]);
+  const double da1 = lane_next(D[a][1]), db1 = lane_next(D[b][1]),
+               dc1 = lane_next(D[c][1]);
   block_update<MODULE>(W[a][2], wa0, wa1, W[b][2], wb0, wb1, W[c][2], wc0, wc1,
                        D[a][2], da0, da1, D[b][2], db0, db1, D[c][2], dc0, dc1,
                        rd0, rd1, rd2, cdr[2], cdr[3], cdr[4], ds);
@@ -150,8 +153,12 @@ __device__ __forceinline__ void stage(double (&W)[7][3], const double (&D)[7][3]
   W[c][0] = lane_prev(wc0, W[c][0]);  W[c][1] = lane_prev(wc1, W[c][1]);
 }
 
+#ifndef WDPM_FUSED_MIN_WAVES
+#define WDPM_FUSED_MIN_WAVES 2   /* waves per SIMD the register allocator must leave room for */
+#endif
+
 template <int MODULE>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, WDPM_FUSED_MIN_WAVES)
 fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout,
                        const double *__restrict__ dem, const SlabGeom g, const int nstrips,
                        const int nitems, const int H, double *__restrict__ totaldrain) {
@@ -254,15 +261,30 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
 __global__ void dpp_probe_kernel(int *out) {
   const int lane = threadIdx.x;
   const double v = (double)lane;
-  out[lane] = (int)lane_next(v, -1.0);
+  out[lane] = (int)lane_next(v);
   out[64 + lane] = (int)lane_prev(v, -2.0);
 }
 
 }  // namespace
 
-/* chunk height in rows (multiple of 3).  Default: enough (strip, chunk) work items to give every
- * SIMD of the 256 CUs several waves, but chunks tall enough that the 6-row warm-up is small. */
-static int pick_chunk_rows(const int rows, const int nstrips, const int override_rows) {
+/* Number of waves of the fused kernel the whole chip holds at once (CUs x blocks/CU x 4 waves),
+ * from the occupancy API; cached per module.  All work items of a launch are made resident
+ * together — one round, no tail — so the item count is sized to this. */
+template <int MODULE>
+static int resident_waves() {
+  static int cached = 0;
+  if (cached) return cached;
+  int dev = 0, cus = 256, blocks = 2;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, fused_iteration_kernel<MODULE>, 256, 0) != hipSuccess || blocks < 1)
+    blocks = 2;
+  cached = cus * blocks * 4;
+  return cached;
+}
+
+/* chunk height in rows (multiple of 3): the rows are cut into as many chunks as keep
+ * strips x chunks within one resident round; each chunk pays a 6-row warm-up. */
+static int pick_chunk_rows(const int rows, const int nstrips, const int override_rows, const int slots) {
   static int env_h = -1;
   if (env_h < 0) {
     const char *e = getenv("WDPM_CHUNK_ROWS");
@@ -274,11 +296,10 @@ static int pick_chunk_rows(const int rows, const int nstrips, const int override
   } else if (env_h >= 3) {
     H = env_h / 3 * 3;
   } else {
-    const int target_items = 256 * 4 * 4;          // CUs x SIMDs x waves
-    int nch = (target_items + nstrips - 1) / nstrips;
+    int nch = slots / nstrips;
     if (nch < 1) nch = 1;
-    H = ((rows + nch - 1) / nch + 2) / 3 * 3;
-    if (H < 48) H = 48;
+    H = ((rows - 2 + nch - 1) / nch + 2) / 3 * 3;
+    if (H < 24) H = 24;
   }
   if (H > rows) H = (rows + 2) / 3 * 3;
   if (H < 3) H = 3;
@@ -300,7 +321,7 @@ static hipError_t dpp_selfcheck(hipStream_t s) {
   if (e != hipSuccess) return e;
   bool ok = true;
   for (int l = 0; l < 64; l++) {
-    ok = ok && h[l] == (l < 63 ? l + 1 : -1);
+    ok = ok && h[l] == (l < 63 ? l + 1 : 0);
     ok = ok && h[64 + l] == (l > 0 ? l - 1 : -2);
   }
   state = ok ? 1 : -1;
@@ -313,7 +334,8 @@ hipError_t wdpm_launch_fused(int module, const double *w_in, double *w_out, cons
   if (e != hipSuccess) return e;
   int nstrips = 1;
   if (g.ncp > kStripIn - kHaloR) nstrips = (g.ncp - (kStripIn - kHaloR) + kStripOut - 1) / kStripOut + 1;
-  const int H = pick_chunk_rows(g.rows, nstrips, chunk_rows);
+  const int slots = module == 2 ? resident_waves<2>() : resident_waves<0>();
+  const int H = pick_chunk_rows(g.rows, nstrips, chunk_rows, slots);
   // chunk i stores rows [H*i+2 (0 for i=0), H*(i+1)+1]; the last must reach row rows-1
   int nchunks = (g.rows - 2 + H - 1) / H;
   if (nchunks < 1) nchunks = 1;

@@ -25,6 +25,22 @@ __host__ __device__ constexpr int nb_dr(int k) { return (k < 3) ? -1 : (k < 5 ? 
 __host__ __device__ constexpr int nb_dc(int k) { return (k < 3) ? k - 1 : (k == 3 ? -1 : (k == 4 ? 1 : k - 6)); }
 
 /* `gate` folds the centre test of the sweep loops (WDPMCL.c:1099) into the transfer condition */
+/* v_min_f64 / v_max_f64 without the canonicalising v_max x,x the compiler adds in IEEE mode.
+ * Same value as the reference's a<b?a:b / a>b?a:b whenever the operands are not NaN and are not
+ * zeros of opposite sign — which holds where the result is used: flow is +0 or positive when a
+ * transfer happens and the centre water is positive (the other case, flow = -inf/NaN next to an
+ * invalid neighbour, is discarded by the `go` select). */
+__device__ __forceinline__ double vmin_f64(const double a, const double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double vmax_f64(const double a, const double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 __device__ __forceinline__ void flow_add(const double dem_c, double &w_c, const double dem_n, double &w_n,
                                          const bool gate = true) {
   const double en = dem_n + w_n;                 // :1946
@@ -32,7 +48,7 @@ __device__ __forceinline__ void flow_add(const double dem_c, double &w_c, const 
   const bool go = gate & (ht > 0);               // :1947
   const double x = (dem_c > en) ? w_c : ht;      // :1948 selects w_c/8 (:1949) or ht/8 (:1955)
   double flow = x * 0.125;
-  flow = (flow < w_c) ? flow : w_c;              // :1957 min(flow, w_c)
+  flow = vmin_f64(flow, w_c);                    // :1957 min(flow, w_c)
   const double wc2 = w_c - flow;                 // :1958
   const double wn2 = w_n + flow;                 // :1959
   w_c = go ? wc2 : w_c;
@@ -47,10 +63,10 @@ __device__ __forceinline__ void flow_drain(const double dem_c, double &w_c, cons
   const bool go = gate & (ht > 0);               // :1989
   const double alt = ((dem_c - dem_n) + (w_c - w_n)) * 0.125;   // :1995-1996
   double flow = (dem_c > nwe) ? w_c * 0.125 : alt;              // :1990-1991
-  flow = (flow > 0.0) ? flow : 0.0;              // :1998 max(flow, 0.0)
-  flow = (flow < w_c) ? flow : w_c;              // :1998 min(.., w_c)
+  flow = vmax_f64(flow, 0.0);                    // :1998 max(flow, 0.0)
+  flow = vmin_f64(flow, w_c);                    // :1998 min(.., w_c)
   double wc2 = w_c - flow;
-  wc2 = (wc2 > 0.0) ? wc2 : 0.0;                 // :1999 max(w_c - flow, 0.0)
+  wc2 = vmax_f64(wc2, 0.0);                      // :1999 max(w_c - flow, 0.0)
   const double wn2 = w_n + flow;                 // :2000
   w_c = go ? wc2 : w_c;
   w_n = go ? wn2 : w_n;
