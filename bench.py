@@ -97,6 +97,10 @@ def main():
     n = args.size
     kernel = {"auto": wdpm_amd.KERNEL_AUTO, "pass": wdpm_amd.KERNEL_PASS, "fused": wdpm_amd.KERNEL_FUSED}[args.kernel]
     transport = DeviceTransport(dist, torch.device("cuda", local_rank)) if world > 1 else None
+    if world > 1 and os.environ.get("WDPM_HALO", "device") == "host":
+        # escape hatch: stage halo rows through host memory over a gloo group
+        from wdpm_amd.rowblock import HostTransport
+        transport = HostTransport(dist, dist.new_group(backend="gloo"))
     solver = RowBlockSolver(lib, "add", n, n, MISSING, rank=rank, nranks=world, exchange_every=args.exchange_every,
                             transport=transport, dist=dist, device=local_rank, kernel=kernel)
     solver.ctx.set_stream(torch.cuda.current_stream().cuda_stream)

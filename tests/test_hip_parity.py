@@ -147,3 +147,36 @@ def test_full_size_properties(hip, n, iters):
     total0, total1 = 0.1 * n * n, float(wf.sum())
     assert abs(total1 - total0) <= 1e-9 * total0
     assert wf[0].max() == 0 and wf[-1].max() == 0 and wf[:, 0].max() == 0 and wf[:, -1].max() == 0
+
+
+def test_torch_view_aliases_library_memory(hip):
+    """the zero-copy tensor view that the RCCL halo exchange sends from / receives into
+    (wdpm_amd/rowblock.py::device_view) really is the library's water raster"""
+    import torch
+    from wdpm_amd.rowblock import device_view
+    dem, water, miss = random_case(21, 40, 30)
+    bd, bw = pad(dem, water, miss)
+    with hip.context(module="add", nrows=40, ncols=30, missingvalue=miss) as g:
+        g.upload(bd, bw)
+        g.set_stream(torch.cuda.current_stream().cuda_stream)
+        g.iterate(3)
+        v = device_view(torch, g.water_ptr(), 42, 32, torch.device("cuda", 0))
+        torch.cuda.synchronize()
+        assert bits_equal(v.cpu().numpy(), g.download_water())
+        # writing through the view is seen by the library (this is what a halo receive does)
+        v[5:7].fill_(0.25)
+        torch.cuda.synchronize()
+        assert (g.download_rows(5, 2) == 0.25).all()
+
+
+def test_rowblock_solver_single_rank_on_gpu(hip, oracle):
+    from wdpm_amd.rowblock import RowBlockSolver
+    dem, water, miss = random_case(22, 90, 200)
+    bd, bw = pad(dem, water, miss)
+    s = RowBlockSolver(hip, "add", 90, 200, miss)
+    s.upload_global(bd, bw)
+    with oracle.context(module="add", nrows=90, ncols=200, missingvalue=miss) as o:
+        o.upload(bd, bw)
+        assert s.run_block(30, 1e-6) == o.run_block(30, 1e-6)
+        assert bits_equal(s.owned_water(), o.download_water())
+    s.close()

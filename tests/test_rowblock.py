@@ -99,3 +99,18 @@ def test_halo_depth_is_sufficient(oracle):
     up1, _ = halo_depth(k - 1)
     assert not bits_equal(owned_after(up1, down), want[lo:hi + 1])   # upward bound is tight
     assert not bits_equal(owned_after(up, 3), want[lo:hi + 1])       # downward one is conservative
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,k", [(2, 1), (3, 3)])
+def test_multirank_hip_slabs_over_gloo(oracle, hip, world, k):
+    """the same decomposition with the HIP back-end: ranks are processes sharing the box's one GPU,
+    halos staged through host memory over gloo (the RCCL transport needs one GPU per rank)."""
+    case = dict(seed=12, R=260, C=400, module="add", k=k, thres=0.005 / 1000, blocks=[14, 9],
+                ctx_kw=dict(device=0))
+    want, mds = single(oracle, case)
+    got = run_ranks(world, case, libpath=hip.path)
+    for g in got:
+        lo, hi = int(g["lo"]), int(g["hi"])
+        assert bits_equal(g["own"], want[lo:hi + 1]), f"rows {lo}..{hi}: {n_bit_diff(g['own'], want[lo:hi + 1])} cells differ"
+        assert list(g["mds"]) == mds

@@ -75,20 +75,20 @@ class HostTransport:
     """Halo rows travel through host numpy buffers and torch.distributed point-to-point ops (gloo).
     Works with any backend library; used by the CPU tests and as a fallback."""
 
-    def __init__(self, dist):
-        self.dist = dist
+    def __init__(self, dist, group=None):
+        self.dist, self.group = dist, group
 
     def exchange(self, ctx: Context, sends, recvs):
         import torch
         ops, bufs = [], []
         for peer, row, n in sends:
             t = torch.from_numpy(ctx.download_rows(row, n))
-            ops.append(self.dist.P2POp(self.dist.isend, t, peer))
+            ops.append(self.dist.P2POp(self.dist.isend, t, peer, self.group))
             bufs.append(t)
         landing = []
         for peer, row, n in recvs:
             t = torch.empty((n, ctx.ncp), dtype=torch.float64)
-            ops.append(self.dist.P2POp(self.dist.irecv, t, peer))
+            ops.append(self.dist.P2POp(self.dist.irecv, t, peer, self.group))
             landing.append((row, t))
         for w in self.dist.batch_isend_irecv(ops):
             w.wait()
@@ -101,6 +101,11 @@ class _DeviceMemory:
 
     def __init__(self, ptr: int, n: int):
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+
+def device_view(torch, ptr: int, rows: int, ncp: int, device):
+    """torch tensor (rows x ncp, fp64) aliasing library-owned device memory at `ptr`"""
+    return torch.as_tensor(_DeviceMemory(ptr, rows * ncp), device=device).view(rows, ncp)
 
 
 class DeviceTransport:
@@ -118,8 +123,7 @@ class DeviceTransport:
         ptr = ctx.water_ptr()
         v = self._views.get(ptr)
         if v is None:
-            n = ctx.slab.rows * ctx.ncp
-            v = self.torch.as_tensor(_DeviceMemory(ptr, n), device=self.device).view(ctx.slab.rows, ctx.ncp)
+            v = device_view(self.torch, ptr, ctx.slab.rows, ctx.ncp, self.device)
             self._views[ptr] = v
         return v
 
