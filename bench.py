@@ -106,6 +106,7 @@ def main():
     solver.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     bd, bw = build_slab_inputs(lib, n, solver.slab)
     solver.ctx.upload(bd, bw)
+    solver.agree_on_options()
     del bd, bw
 
     def sync():

@@ -123,6 +123,17 @@ int wdpm_synchronize(wdpm_ctx *ctx);
 int wdpm_timing_reset(wdpm_ctx *ctx);
 int wdpm_timing_get(wdpm_ctx *ctx, int64_t *launches, double *ms);
 
+/* -- options -----------------------------------------------------------------------------------
+ * WDPM_OPT_SIGNED_ZERO_SAFE (get/set): 1 = the add/subtract stencil must preserve the sign of
+ *   zero-depth cells.  The library sets it by itself when an uploaded water raster contains -0.0
+ *   (it then runs the kernel variant that keeps the reference's conditional updates); otherwise the
+ *   faster variant, which is bit-identical whenever no -0.0 is present (none can be created), runs.
+ *   A multi-GPU driver whose transport writes halo rows straight into device memory must OR the
+ *   flag over all ranks and set it (wdpm_amd/rowblock.py does). */
+enum { WDPM_OPT_SIGNED_ZERO_SAFE = 1 };
+int wdpm_get_option(wdpm_ctx *ctx, int32_t key, int64_t *value);
+int wdpm_set_option(wdpm_ctx *ctx, int32_t key, int64_t value);
+
 /* -- synthetic DEM generator: integer-seeded, identical on every
  * host.  Writes an n x n UNPADDED row-major raster. */
 int wdpm_synth_dem(int32_t n, uint64_t seed, double *dem);

@@ -180,3 +180,48 @@ def test_rowblock_solver_single_rank_on_gpu(hip, oracle):
         assert s.run_block(30, 1e-6) == o.run_block(30, 1e-6)
         assert bits_equal(s.owned_water(), o.download_water())
     s.close()
+
+
+def test_negative_zero_depths_keep_their_sign(hip, oracle):
+    """a -0.0 depth in the input makes the library pick the sign-preserving stencil variant by
+    itself; results equal the oracle bit for bit, sign of zero included"""
+    dem, water, miss = random_case(31, 60, 220, dry_frac=0.5)
+    water[(water == 0) & (np.arange(water.size).reshape(water.shape) % 3 == 0)] = -0.0
+    bd, bw = pad(dem, water, miss)
+    assert np.signbit(bw[bw == 0]).any()
+    kw = dict(module="add", nrows=60, ncols=220, missingvalue=miss)
+    with hip.context(**kw) as g, oracle.context(**kw) as o:
+        g.upload(bd, bw)
+        o.upload(bd, bw)
+        assert g.get_option(wdpm_amd.OPT_SIGNED_ZERO_SAFE) == 1
+        g.iterate(7)
+        o.iterate(7)
+        assert n_bit_diff(g.download_water(), o.download_water()) == 0
+        # a later upload without -0.0 goes back to the fast variant, still exact
+        g.upload(bd, np.abs(bw))
+        o.upload(bd, np.abs(bw))
+        assert g.get_option(wdpm_amd.OPT_SIGNED_ZERO_SAFE) == 0
+        g.iterate(7)
+        o.iterate(7)
+        assert n_bit_diff(g.download_water(), o.download_water()) == 0
+        # and forcing the safe variant on clean data gives the same bits again
+        g.upload(bd, np.abs(bw))
+        g.set_option(wdpm_amd.OPT_SIGNED_ZERO_SAFE, 1)
+        g.iterate(7)
+        assert n_bit_diff(g.download_water(), o.download_water()) == 0
+
+
+def test_negative_and_nan_inputs_are_handled_like_the_reference(hip, oracle):
+    """odd water files: negative depths and NaN cells never give water and are carried through"""
+    dem, water, miss = random_case(32, 40, 200)
+    water[3, 5] = -0.25
+    water[10, 100] = np.nan
+    water[20:22, 50:60] = -1e-9
+    bd, bw = pad(dem, water, miss)
+    kw = dict(module="add", nrows=40, ncols=200, missingvalue=miss)
+    with hip.context(**kw) as g, oracle.context(**kw) as o:
+        g.upload(bd, bw)
+        o.upload(bd, bw)
+        g.iterate(5)
+        o.iterate(5)
+        assert bits_equal(g.download_water(), o.download_water())

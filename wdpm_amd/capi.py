@@ -16,6 +16,7 @@ import numpy as np
 ADD, SUBTRACT, DRAIN = 0, 1, 2
 MODULES = {"add": ADD, "subtract": SUBTRACT, "drain": DRAIN}
 KERNEL_AUTO, KERNEL_PASS, KERNEL_FUSED = 0, 1, 2
+OPT_SIGNED_ZERO_SAFE = 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # WDPM_HIP_LIB lets a tuning run point at an alternative build of the same HIP library
@@ -62,12 +63,41 @@ SYMBOLS = {
     "wdpm_synchronize": (C.c_int, [_vp]),
     "wdpm_timing_reset": (C.c_int, [_vp]),
     "wdpm_timing_get": (C.c_int, [_vp, C.POINTER(C.c_int64), _dp]),
+    "wdpm_get_option": (C.c_int, [_vp, C.c_int32, C.POINTER(C.c_int64)]),
+    "wdpm_set_option": (C.c_int, [_vp, C.c_int32, C.c_int64]),
     "wdpm_synth_dem": (C.c_int, [C.c_int32, C.c_uint64, _vp]),
 }
 
 
 class WdpmError(RuntimeError):
     pass
+
+
+_runtime_preloaded = False
+
+
+def _preload_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch wheels bundle their own libamdhip64.so (SONAME
+    libamdhip64.so.7) and load it by file name; libwdpm_hip.so needs libamdhip64.so.7 by SONAME.
+    If our library came first the dynamic linker would map /opt/rocm's copy and torch would later
+    map its own beside it — two runtimes, and stream handles / device pointers shared between
+    torch (RCCL halo exchange) and this library would be meaningless.  Mapping torch's copy first
+    (without importing torch) makes both resolve to the same runtime.  No torch, no preload: the
+    system runtime is used, as the C command line does."""
+    global _runtime_preloaded
+    if _runtime_preloaded or os.environ.get("WDPM_NO_TORCH_RUNTIME"):
+        return
+    _runtime_preloaded = True
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
 
 
 class Lib:
@@ -77,6 +107,7 @@ class Lib:
         if not os.path.exists(path):
             raise WdpmError(f"wdpm library not found: {path}")
         self.path = path
+        _preload_torch_hip_runtime()
         self.dll = C.CDLL(path)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(self.dll, name)  # AttributeError if the symbol is not exported
@@ -233,6 +264,14 @@ class Context:
 
     def set_stream(self, stream_handle: int):
         self.lib.check(self.lib.dll.wdpm_set_stream(self._h, C.c_void_p(stream_handle)))
+
+    def get_option(self, key: int) -> int:
+        v = C.c_int64()
+        self.lib.check(self.lib.dll.wdpm_get_option(self._h, key, C.byref(v)))
+        return v.value
+
+    def set_option(self, key: int, value: int):
+        self.lib.check(self.lib.dll.wdpm_set_option(self._h, key, value))
 
     def synchronize(self):
         self.lib.check(self.lib.dll.wdpm_synchronize(self._h))

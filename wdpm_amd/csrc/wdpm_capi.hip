@@ -52,6 +52,7 @@ struct wdpm_ctx {
   double *h_pin;                /* pinned staging: 4 doubles */
   std::vector<double> h_dem;    /* host copy of dem, kept only for wdpm_drain_stats */
   int kernel;                   /* resolved WDPM_KERNEL_* */
+  bool signed_zero_safe;        /* a -0.0 depth was uploaded (or the caller asked): exact-zero stencil variant */
   /* stencil timing */
   std::vector<EventPair> pending;
   std::vector<EventPair> pool;
@@ -99,6 +100,7 @@ int wdpm_create(wdpm_ctx **out, const wdpm_params *p) {
   x->cells = (size_t)rows * x->g.ncp;
   x->kernel = p->kernel == WDPM_KERNEL_AUTO ? WDPM_KERNEL_FUSED : p->kernel;
   x->cur = 0;
+  x->signed_zero_safe = false;
   x->launches = 0;
   x->ms = 0.0;
   x->d_dem = x->d_w[0] = x->d_w[1] = x->d_old = nullptr;
@@ -154,13 +156,26 @@ int wdpm_synchronize(wdpm_ctx *x) {
 }
 
 /* ---- data movement ---------------------------------------------------------------------- */
+/* after water has been written to rows [row, row+nrows): does it hold a -0.0? */
+static int note_negzero(wdpm_ctx *x, int row, int nrows) {
+  HIP_TRY(hipMemsetAsync(x->d_bits, 0, sizeof(unsigned long long), x->stream));
+  HIP_TRY(wdpm_launch_scan_negzero(x->d_w[x->cur] + (size_t)row * x->g.ncp, (size_t)nrows * x->g.ncp, x->d_bits, x->stream));
+  HIP_TRY(hipMemcpyAsync(x->h_pin, x->d_bits, sizeof(double), hipMemcpyDeviceToHost, x->stream));
+  HIP_TRY(hipStreamSynchronize(x->stream));
+  unsigned long long bits;
+  memcpy(&bits, x->h_pin, sizeof bits);
+  if (bits) x->signed_zero_safe = true;
+  return 0;
+}
+
 int wdpm_upload(wdpm_ctx *x, const double *bigdem, const double *bigwater) {
   if (!bigdem || !bigwater) return fail("wdpm_upload: null array");
   if (bind(x)) return 1;
   const size_t bytes = x->cells * sizeof(double);
   HIP_TRY(hipMemcpyAsync(x->d_dem, bigdem, bytes, hipMemcpyHostToDevice, x->stream));
   HIP_TRY(hipMemcpyAsync(x->d_w[x->cur], bigwater, bytes, hipMemcpyHostToDevice, x->stream));
-  HIP_TRY(hipStreamSynchronize(x->stream));
+  x->signed_zero_safe = false;
+  if (note_negzero(x, 0, x->g.rows)) return 1;
   if (x->p.module == WDPM_DRAIN) x->h_dem.assign(bigdem, bigdem + x->cells);
   return 0;
 }
@@ -169,8 +184,8 @@ int wdpm_upload_water(wdpm_ctx *x, const double *bigwater) {
   if (!bigwater) return fail("wdpm_upload_water: null array");
   if (bind(x)) return 1;
   HIP_TRY(hipMemcpyAsync(x->d_w[x->cur], bigwater, x->cells * sizeof(double), hipMemcpyHostToDevice, x->stream));
-  HIP_TRY(hipStreamSynchronize(x->stream));
-  return 0;
+  x->signed_zero_safe = false;
+  return note_negzero(x, 0, x->g.rows);
 }
 
 int wdpm_download_water(wdpm_ctx *x, double *bigwater) {
@@ -195,7 +210,18 @@ int wdpm_upload_rows(wdpm_ctx *x, int32_t row, int32_t nrows, const double *src)
   if (bind(x)) return 1;
   HIP_TRY(hipMemcpyAsync(x->d_w[x->cur] + (size_t)row * x->g.ncp, src, (size_t)nrows * x->g.ncp * sizeof(double),
                          hipMemcpyHostToDevice, x->stream));
-  HIP_TRY(hipStreamSynchronize(x->stream));
+  return note_negzero(x, row, nrows);
+}
+
+int wdpm_get_option(wdpm_ctx *x, int32_t key, int64_t *value) {
+  if (key != WDPM_OPT_SIGNED_ZERO_SAFE || !value) return fail("wdpm_get_option: unknown option %d", key);
+  *value = x->signed_zero_safe ? 1 : 0;
+  return 0;
+}
+
+int wdpm_set_option(wdpm_ctx *x, int32_t key, int64_t value) {
+  if (key != WDPM_OPT_SIGNED_ZERO_SAFE) return fail("wdpm_set_option: unknown option %d", key);
+  x->signed_zero_safe = value != 0;
   return 0;
 }
 
@@ -267,7 +293,8 @@ int wdpm_iterate(wdpm_ctx *x, int32_t n_iter) {
   HIP_TRY(hipEventRecord(ep.a, x->stream));
   for (int it = 0; it < n_iter; it++) {
     if (x->kernel == WDPM_KERNEL_FUSED) {
-      HIP_TRY(wdpm_launch_fused(x->p.module, x->d_w[x->cur], x->d_w[x->cur ^ 1], x->d_dem, x->g, x->p.chunk_rows, x->d_scal, x->stream));
+      HIP_TRY(wdpm_launch_fused(x->p.module, x->d_w[x->cur], x->d_w[x->cur ^ 1], x->d_dem, x->g, x->p.chunk_rows,
+                                x->signed_zero_safe ? 1 : 0, x->d_scal, x->stream));
       x->cur ^= 1;
       x->launches += 1;
     } else {

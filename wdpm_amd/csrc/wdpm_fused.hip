@@ -85,7 +85,7 @@ __device__ __forceinline__ void step_drain(const double dc, double &wc, const do
 }
 
 /* one 3x3 block of one colour pass: centre (1,1), neighbours in row-major order */
-template <int MODULE>
+template <int MODULE, bool SZ_SAFE>
 __device__ __forceinline__ void block_update(
     double &w00, double &w01, double &w02, double &w10, double &w11, double &w12, double &w20, double &w21,
     double &w22, const double d00, const double d01, const double d02, const double d10, const double d11,
@@ -108,6 +108,17 @@ __device__ __forceinline__ void block_update(
     // at most one lane of the wave holds the outlet in this pass: make its totaldrain the wave's
     const unsigned long long m = __ballot(ds.hit);
     if (m) ds.td = wave_read(ds.td, __ffsll((long long)m) - 1);
+  } else if (!SZ_SAFE) {
+    // no -0.0 in the raster: the gate rides on the centre elevation (see flow_add_nz)
+    const double dce = gate ? d11 : -WDPM_INF;
+    flow_add_nz(dce, wc, d00, w00);
+    flow_add_nz(dce, wc, d01, w01);
+    flow_add_nz(dce, wc, d02, w02);
+    flow_add_nz(dce, wc, d10, w10);
+    flow_add_nz(dce, wc, d12, w12);
+    flow_add_nz(dce, wc, d20, w20);
+    flow_add_nz(dce, wc, d21, w21);
+    flow_add_nz(dce, wc, d22, w22);
   } else {
     flow_add(d11, wc, d00, w00, gate);
     flow_add(d11, wc, d01, w01, gate);
@@ -122,7 +133,7 @@ __device__ __forceinline__ void block_update(
 }
 
 /* the three column alignments oj = 1,2,3 of one row alignment, on window slots S0..S0+2 */
-template <int MODULE, int S0>
+template <int MODULE, bool SZ_SAFE, int S0>
 __device__ __forceinline__ void stage(double (&W)[7][3], const double (&D)[7][3], const int row_s0,
                                       const int drain_row, const bool (&cdr)[5], DrainState &ds) {
   const bool rd0 = MODULE == 2 && row_s0 == drain_row;
@@ -130,21 +141,21 @@ __device__ __forceinline__ void stage(double (&W)[7][3], const double (&D)[7][3]
   const bool rd2 = MODULE == 2 && row_s0 + 2 == drain_row;
   constexpr int a = S0, b = S0 + 1, c = S0 + 2;
   // oj = 1: own columns 0,1,2
-  block_update<MODULE>(W[a][0], W[a][1], W[a][2], W[b][0], W[b][1], W[b][2], W[c][0], W[c][1], W[c][2],
+  block_update<MODULE, SZ_SAFE>(W[a][0], W[a][1], W[a][2], W[b][0], W[b][1], W[b][2], W[c][0], W[c][1], W[c][2],
                        D[a][0], D[a][1], D[a][2], D[b][0], D[b][1], D[b][2], D[c][0], D[c][1], D[c][2],
                        rd0, rd1, rd2, cdr[0], cdr[1], cdr[2], ds);
   // oj = 2: own columns 1,2 + column 0 of the next lane
   double wa0 = lane_next(W[a][0]), wb0 = lane_next(W[b][0]), wc0 = lane_next(W[c][0]);
   const double da0 = lane_next(D[a][0]), db0 = lane_next(D[b][0]),
                dc0 = lane_next(D[c][0]);
-  block_update<MODULE>(W[a][1], W[a][2], wa0, W[b][1], W[b][2], wb0, W[c][1], W[c][2], wc0,
+  block_update<MODULE, SZ_SAFE>(W[a][1], W[a][2], wa0, W[b][1], W[b][2], wb0, W[c][1], W[c][2], wc0,
                        D[a][1], D[a][2], da0, D[b][1], D[b][2], db0, D[c][1], D[c][2], dc0,
                        rd0, rd1, rd2, cdr[1], cdr[2], cdr[3], ds);
   // oj = 3: own column 2 + columns 0,1 of the next lane
   double wa1 = lane_next(W[a][1]), wb1 = lane_next(W[b][1]), wc1 = lane_next(W[c][1]);
   const double da1 = lane_next(D[a][1]), db1 = lane_next(D[b][1]),
                dc1 = lane_next(D[c][1]);
-  block_update<MODULE>(W[a][2], wa0, wa1, W[b][2], wb0, wb1, W[c][2], wc0, wc1,
+  block_update<MODULE, SZ_SAFE>(W[a][2], wa0, wa1, W[b][2], wb0, wb1, W[c][2], wc0, wc1,
                        D[a][2], da0, da1, D[b][2], db0, db1, D[c][2], dc0, dc1,
                        rd0, rd1, rd2, cdr[2], cdr[3], cdr[4], ds);
   // hand the borrowed columns back to lane+1; lane 0 keeps its own (nothing to its left)
@@ -157,7 +168,7 @@ __device__ __forceinline__ void stage(double (&W)[7][3], const double (&D)[7][3]
 #define WDPM_FUSED_MIN_WAVES 2   /* waves per SIMD the register allocator must leave room for */
 #endif
 
-template <int MODULE>
+template <int MODULE, bool SZ_SAFE>
 __global__ void __launch_bounds__(256, WDPM_FUSED_MIN_WAVES)
 fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout,
                        const double *__restrict__ dem, const SlabGeom g, const int nstrips,
@@ -227,9 +238,9 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
     if (n + 1 < nsteps) prefetch(A + 3 * (n + 1));
 
     const int rbase = A + 3 * n - 4;                 // slab row of window slot 0
-    stage<MODULE, 4>(W, D, rbase + 4, g.dr, cdr, ds);   // oi = 1 on rows 3n   .. 3n+2
-    stage<MODULE, 2>(W, D, rbase + 2, g.dr, cdr, ds);   // oi = 2 on rows 3n-2 .. 3n
-    stage<MODULE, 0>(W, D, rbase + 0, g.dr, cdr, ds);   // oi = 3 on rows 3n-4 .. 3n-2
+    stage<MODULE, SZ_SAFE, 4>(W, D, rbase + 4, g.dr, cdr, ds);   // oi = 1 on rows 3n   .. 3n+2
+    stage<MODULE, SZ_SAFE, 2>(W, D, rbase + 2, g.dr, cdr, ds);   // oi = 2 on rows 3n-2 .. 3n
+    stage<MODULE, SZ_SAFE, 0>(W, D, rbase + 0, g.dr, cdr, ds);   // oi = 3 on rows 3n-4 .. 3n-2
 
     // rows 3n-4 .. 3n-2 have now seen all nine passes
 #pragma unroll
@@ -270,13 +281,13 @@ __global__ void dpp_probe_kernel(int *out) {
 /* Number of waves of the fused kernel the whole chip holds at once (CUs x blocks/CU x 4 waves),
  * from the occupancy API; cached per module.  All work items of a launch are made resident
  * together — one round, no tail — so the item count is sized to this. */
-template <int MODULE>
+template <int MODULE, bool SZ_SAFE>
 static int resident_waves() {
   static int cached = 0;
   if (cached) return cached;
   int dev = 0, cus = 256, blocks = 2;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, fused_iteration_kernel<MODULE>, 256, 0) != hipSuccess || blocks < 1)
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, fused_iteration_kernel<MODULE, SZ_SAFE>, 256, 0) != hipSuccess || blocks < 1)
     blocks = 2;
   cached = cus * blocks * 4;
   return cached;
@@ -329,12 +340,14 @@ static hipError_t dpp_selfcheck(hipStream_t s) {
 }
 
 hipError_t wdpm_launch_fused(int module, const double *w_in, double *w_out, const double *dem,
-                             const SlabGeom &g, int chunk_rows, double *totaldrain, hipStream_t s) {
+                             const SlabGeom &g, int chunk_rows, int signed_zero_safe, double *totaldrain,
+                             hipStream_t s) {
   hipError_t e = dpp_selfcheck(s);
   if (e != hipSuccess) return e;
   int nstrips = 1;
   if (g.ncp > kStripIn - kHaloR) nstrips = (g.ncp - (kStripIn - kHaloR) + kStripOut - 1) / kStripOut + 1;
-  const int slots = module == 2 ? resident_waves<2>() : resident_waves<0>();
+  const bool fast = module != 2 && !signed_zero_safe;
+  const int slots = module == 2 ? resident_waves<2, true>() : fast ? resident_waves<0, false>() : resident_waves<0, true>();
   const int H = pick_chunk_rows(g.rows, nstrips, chunk_rows, slots);
   // chunk i stores rows [H*i+2 (0 for i=0), H*(i+1)+1]; the last must reach row rows-1
   int nchunks = (g.rows - 2 + H - 1) / H;
@@ -342,8 +355,10 @@ hipError_t wdpm_launch_fused(int module, const double *w_in, double *w_out, cons
   const int nitems = nstrips * nchunks;
   const dim3 grid((nitems + 3) / 4), block(256);
   if (module == 2)
-    hipLaunchKernelGGL(fused_iteration_kernel<2>, grid, block, 0, s, w_in, w_out, dem, g, nstrips, nitems, H, totaldrain);
+    hipLaunchKernelGGL((fused_iteration_kernel<2, true>), grid, block, 0, s, w_in, w_out, dem, g, nstrips, nitems, H, totaldrain);
+  else if (fast)
+    hipLaunchKernelGGL((fused_iteration_kernel<0, false>), grid, block, 0, s, w_in, w_out, dem, g, nstrips, nitems, H, totaldrain);
   else
-    hipLaunchKernelGGL(fused_iteration_kernel<0>, grid, block, 0, s, w_in, w_out, dem, g, nstrips, nitems, H, totaldrain);
+    hipLaunchKernelGGL((fused_iteration_kernel<0, true>), grid, block, 0, s, w_in, w_out, dem, g, nstrips, nitems, H, totaldrain);
   return hipGetLastError();
 }

@@ -23,8 +23,13 @@ struct SlabGeom {
 hipError_t wdpm_launch_pass(int module, double *w, const double *dem, const SlabGeom &g, int oi, int oj,
                             double *totaldrain, hipStream_t s);
 /* one whole iteration (9 passes) fused in one launch: w_in -> w_out (distinct buffers) */
+/* signed_zero_safe = 0 selects the faster add/subtract variant that is exact when the water raster
+ * holds no -0.0 (wdpm_stencil.h::flow_add_nz) */
 hipError_t wdpm_launch_fused(int module, const double *w_in, double *w_out, const double *dem,
-                             const SlabGeom &g, int chunk_rows, double *totaldrain, hipStream_t s);
+                             const SlabGeom &g, int chunk_rows, int signed_zero_safe, double *totaldrain,
+                             hipStream_t s);
+/* *flag |= 1 if any of the n doubles at p is -0.0 */
+hipError_t wdpm_launch_scan_negzero(const double *p, size_t n, unsigned long long *flag, hipStream_t s);
 /* drain() (WDPMCL.c:1859-1897) on the device */
 hipError_t wdpm_launch_drain_outlet(double *w, const double *dem, const SlabGeom &g, double *totaldrain,
                                     hipStream_t s);

@@ -131,6 +131,26 @@ hipError_t wdpm_launch_flush_snapshot(double *w, double *old, size_t cells, doub
 }
 
 // ---------------------------------------------------------------------------------------------
+// does the raster hold a negative zero?  (decides which add/subtract stencil variant is exact)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+scan_negzero_kernel(const double *__restrict__ p, size_t n, unsigned long long *flag) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  bool hit = false;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    hit |= (unsigned long long)__double_as_longlong(p[i]) == 0x8000000000000000ull;
+  if (__ballot(hit) && (threadIdx.x & 63) == 0) atomicOr(flag, 1ull);
+}
+
+hipError_t wdpm_launch_scan_negzero(const double *p, size_t n, unsigned long long *flag, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(scan_negzero_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, n, flag);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // max_diff: per-lane running max with the reference's "if (d > m) m = d" (NaN never wins),
 // wave64 xor-shuffle reduction, LDS across the 4 waves, one atomicMax per workgroup.
 // ---------------------------------------------------------------------------------------------

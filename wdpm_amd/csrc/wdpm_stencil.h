@@ -49,10 +49,44 @@ __device__ __forceinline__ void flow_add(const double dem_c, double &w_c, const 
   const double x = (dem_c > en) ? w_c : ht;      // :1948 selects w_c/8 (:1949) or ht/8 (:1955)
   double flow = x * 0.125;
   flow = vmin_f64(flow, w_c);                    // :1957 min(flow, w_c)
-  const double wc2 = w_c - flow;                 // :1958
-  const double wn2 = w_n + flow;                 // :1959
-  w_c = go ? wc2 : w_c;
-  w_n = go ? wn2 : w_n;
+  // One select instead of two: when no transfer happens the flow becomes -0.0, and
+  //   w_n + (-0.0) == w_n   and   w_c - |-0.0| == w_c - (+0.0) == w_c
+  // hold bit-for-bit for EVERY double (signed zeros, infinities and NaN payloads included), so
+  // the unconditional updates below equal the reference's conditional ones (:1958-1959).  When a
+  // transfer happens flow >= +0, hence |flow| == flow.  |.| is a free VOP3 source modifier.
+  const double fsel = go ? flow : -0.0;
+  w_c = w_c - __builtin_fabs(fsel);              // :1958
+  w_n = w_n + fsel;                              // :1959
+}
+
+/* flow_add_nz — the same neighbour step in 10 VALU instructions instead of 13, bit-identical to
+ * flow_add whenever the water raster holds no negative zero (the caller guarantees it: the
+ * library scans every upload, and no operation of the loop can create a -0.0 depth).
+ *
+ * `dem_c` must already carry the centre gate: the caller passes -inf for a centre that may not
+ * give water (dry, NODATA or outside the slab), which makes ht_diff -inf for every neighbour.
+ *
+ *   reference (:1947-1959)                     here
+ *   if (ht > 0) { flow = ...; }                f = max(x/8, -0.0)     no compare, no mask
+ *   flow = min(flow, w_c)                      dropped: a no-op, see (b)
+ *
+ * (a) no transfer (ht <= 0, -inf or NaN): dem_c > en is false [dem_c > en implies ht > 0 for
+ *     w_c >= 0, because fl(dem_c+w_c) >= dem_c > en and distinct doubles never subtract to 0],
+ *     so x = ht and f = max(ht/8, -0.0) is -0.0 (or +0.0 when ht == +0): w_n + f == w_n for every
+ *     w_n except -0.0 (+0.0 case) — excluded — and w_c - |f| == w_c always.
+ * (b) transfer (ht > 0, w_c > 0): x/8 <= w_c, so the reference's min() returns x/8:
+ *     for x = w_c trivially; for x = ht (dem_c <= en): with a = fl(dem_c + w_c),
+ *     ht = fl(a - en) <= fl(a - dem_c) and a - dem_c <= w_c + ulp(a)/2; ht > 0 needs a != dem_c,
+ *     i.e. w_c >= ulp(a)/2 (or w_c dominates), hence ht <= 2 w_c (1 + 2^-53) < 8 w_c.
+ * tests/test_stencil_forms.py checks (a),(b) on ~10^8 adversarial operand tuples against the
+ * reference form, and the GPU parity tests run this variant on every golden vector. */
+__device__ __forceinline__ void flow_add_nz(const double dem_c, double &w_c, const double dem_n, double &w_n) {
+  const double en = dem_n + w_n;                 // :1946
+  const double ht = (dem_c + w_c) - en;          // :1945-1946
+  const double x = (dem_c > en) ? w_c : ht;      // :1948-1955
+  const double f = vmax_f64(x * 0.125, -0.0);    // :1947 + :1949/:1955 (+ :1957, a no-op)
+  w_c = w_c - __builtin_fabs(f);                 // :1958
+  w_n = w_n + f;                                 // :1959
 }
 
 __device__ __forceinline__ void flow_drain(const double dem_c, double &w_c, const double dem_n, double &w_n,

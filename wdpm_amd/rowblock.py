@@ -162,6 +162,20 @@ class RowBlockSolver:
         s = self.slab
         self.ctx.upload(bigdem[s.row0:s.row0 + s.rows], bigwater[s.row0:s.row0 + s.rows])
         self._since_exchange = 0
+        self.agree_on_options()
+
+    def agree_on_options(self):
+        """A -0.0 depth anywhere in the raster makes every rank use the sign-preserving stencil
+        variant (halo rows may be written straight into device memory by the transport, past the
+        library's own upload scan)."""
+        if self.nranks > 1:
+            import torch
+            from .capi import OPT_SIGNED_ZERO_SAFE
+            t = torch.tensor([self.ctx.get_option(OPT_SIGNED_ZERO_SAFE)], dtype=torch.int64)
+            if self.dist.get_backend() == "nccl":
+                t = t.cuda()
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            self.ctx.set_option(OPT_SIGNED_ZERO_SAFE, int(t.item()))
 
     def owned_water(self) -> np.ndarray:
         s = self.slab
