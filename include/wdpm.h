@@ -114,7 +114,7 @@ int wdpm_run_block(wdpm_ctx *ctx, int32_t n_iter, double thres, double *max_diff
 /* -- plumbing for multi-GPU drivers (product library; the oracle returns host pointers) ------ */
 /* device pointer of the CURRENT water raster (changes after every wdpm_iterate/wdpm_pass) */
 int wdpm_water_ptr(wdpm_ctx *ctx, void **ptr);
-int wdpm_dem_ptr(wdpm_ctx *ctx, void **ptr);
+int wdpm_dem_ptr(wdpm_ctx *ctx, void **ptr);   /* device copy: NODATA cells hold +inf */
 /* run all work of this context on the caller's hipStream_t (e.g. torch's current stream) */
 int wdpm_set_stream(wdpm_ctx *ctx, void *hip_stream);
 int wdpm_synchronize(wdpm_ctx *ctx);

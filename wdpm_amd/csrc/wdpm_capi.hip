@@ -2,7 +2,7 @@
  * wdpm_capi.hip — the C ABI of include/wdpm.h implemented on HIP for gfx950.
  *
  * One context = one raster slab resident in one GPU's HBM for the context's lifetime:
- *   dem      rows x (C+2) fp64   read-only after upload
+ *   dem      rows x (C+2) fp64   read-only after upload; NODATA cells are rewritten to +inf on the device
  *   water[2] rows x (C+2) fp64   ping-pong pair (the fused kernel reads one, writes the other)
  *   old      rows x (C+2) fp64   snapshot for the convergence test
  *   scal     {totaldrain, olddrain} fp64 + one uint64 reduction cell
@@ -50,7 +50,7 @@ struct wdpm_ctx {
   double *d_scal;               /* [0] totaldrain, [1] olddrain */
   unsigned long long *d_bits;   /* max-diff reduction cell */
   double *h_pin;                /* pinned staging: 4 doubles */
-  std::vector<double> h_dem;    /* host copy of dem, kept only for wdpm_drain_stats */
+  std::vector<unsigned char> h_valid; /* bigdem > missingvalue per cell, kept only for wdpm_drain_stats */
   int kernel;                   /* resolved WDPM_KERNEL_* */
   bool signed_zero_safe;        /* a -0.0 depth was uploaded (or the caller asked): exact-zero stencil variant */
   /* stencil timing */
@@ -174,9 +174,13 @@ int wdpm_upload(wdpm_ctx *x, const double *bigdem, const double *bigwater) {
   const size_t bytes = x->cells * sizeof(double);
   HIP_TRY(hipMemcpyAsync(x->d_dem, bigdem, bytes, hipMemcpyHostToDevice, x->stream));
   HIP_TRY(hipMemcpyAsync(x->d_w[x->cur], bigwater, bytes, hipMemcpyHostToDevice, x->stream));
+  HIP_TRY(wdpm_launch_mark_nodata(x->d_dem, x->cells, x->g.miss, x->stream));
   x->signed_zero_safe = false;
   if (note_negzero(x, 0, x->g.rows)) return 1;
-  if (x->p.module == WDPM_DRAIN) x->h_dem.assign(bigdem, bigdem + x->cells);
+  if (x->p.module == WDPM_DRAIN) {
+    x->h_valid.resize(x->cells);
+    for (size_t i = 0; i < x->cells; i++) x->h_valid[i] = bigdem[i] > x->g.miss;
+  }
   return 0;
 }
 
@@ -332,17 +336,13 @@ int wdpm_drain_stats(wdpm_ctx *x, double *diffdrain, double *final_sum) {
     *diffdrain = fabs(x->h_pin[0] - x->h_pin[1]);
   }
   if (final_sum) {
-    if (x->h_dem.size() != x->cells) {
-      x->h_dem.resize(x->cells);
-      HIP_TRY(hipMemcpyAsync(x->h_dem.data(), x->d_dem, x->cells * sizeof(double), hipMemcpyDeviceToHost, x->stream));
-    }
+    if (x->h_valid.size() != x->cells) return fail("wdpm_drain_stats: no DEM has been uploaded to this drain context");
     std::vector<double> w(x->cells);
     HIP_TRY(hipMemcpyAsync(w.data(), x->d_w[x->cur], x->cells * sizeof(double), hipMemcpyDeviceToHost, x->stream));
     HIP_TRY(hipStreamSynchronize(x->stream));
     double s = 0;
-    const double miss = x->g.miss;
     for (size_t i = 0; i < x->cells; i++)
-      if (x->h_dem[i] > miss) s += w[i];
+      if (x->h_valid[i]) s += w[i];
     *final_sum = s;
   }
   return 0;

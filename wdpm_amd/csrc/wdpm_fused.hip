@@ -187,12 +187,15 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
   if (or_hi > g.rows - 1) or_hi = g.rows - 1;
 
   const int colb = c0 + 3 * lane;
-  bool colok[3], stok[3];
+  // store side: after the LDS transpose lane l holds columns c0 + l + 64k, k = 0,1,2
+  bool st_ok[3];
 #pragma unroll
-  for (int j = 0; j < 3; j++) {
-    colok[j] = colb + j < g.ncp;
-    stok[j] = colok[j] && colb + j >= oc_lo && colb + j <= oc_hi;
+  for (int k = 0; k < 3; k++) {
+    const int col = c0 + 64 * k + lane;
+    st_ok[k] = col < g.ncp && col >= oc_lo && col <= oc_hi;
   }
+  __shared__ double stage_all[4][3 * kStripIn];          // 4.5 KiB per wave, private to the wave
+  double *const stage_lds = stage_all[threadIdx.x >> 6];
   bool cdr[5];
 #pragma unroll
   for (int j = 0; j < 5; j++) cdr[j] = MODULE == 2 && colb + j == g.dc;
@@ -206,35 +209,69 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
 #pragma unroll
     for (int j = 0; j < 3; j++) { W[k][j] = 0.0; D[k][j] = WDPM_INF; }
 
+  // Only waves of the last strip / last chunk can touch cells outside the slab; every other wave
+  // loads without any predicate.  `edge` is wave-uniform.
+  const bool edge = (c0 + kStripIn > g.ncp) || (A + 3 * nsteps > g.rows);
+  const size_t pitch = (size_t)g.ncp;
+  // running pointers to the first of the three rows to prefetch next (interior waves only)
+  const double *pw = win + (size_t)A * pitch + (edge ? 0 : colb);
+  const double *pd = dem + (size_t)A * pitch + (edge ? 0 : colb);
+  int cclamp[3];                                               // edge waves: per-column clamped index
+#pragma unroll
+  for (int j = 0; j < 3; j++) cclamp[j] = colb + j < g.ncp ? colb + j : g.ncp - 1;
+
   // raw prefetch registers for the next step's three rows
   double NW[3][3], ND[3][3];
-  bool nrow_ok[3];
   auto prefetch = [&](const int r0) {
+    if (!edge) {
 #pragma unroll
-    for (int i = 0; i < 3; i++) {
-      const int r = r0 + i;
-      nrow_ok[i] = r < g.rows;
-      const size_t rowoff = (size_t)(nrow_ok[i] ? r : 0) * g.ncp;
+      for (int i = 0; i < 3; i++)
 #pragma unroll
-      for (int j = 0; j < 3; j++) {
-        const size_t off = rowoff + (colok[j] ? colb + j : 0);
-        NW[i][j] = win[off];
-        ND[i][j] = dem[off];
+        for (int j = 0; j < 3; j++) {
+          NW[i][j] = pw[i * pitch + j];
+          ND[i][j] = pd[i * pitch + j];
+        }
+#ifndef WDPM_ABLATE_LOADS   /* timing experiment only: re-read the same three rows (cache hits) */
+      pw += 3 * pitch;
+      pd += 3 * pitch;
+#endif
+    } else {
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        const int r = r0 + i < g.rows ? r0 + i : g.rows - 1;    // clamped, masked on use
+        const size_t off = (size_t)r * pitch;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          NW[i][j] = win[off + cclamp[j]];
+          ND[i][j] = dem[off + cclamp[j]];
+        }
       }
     }
   };
   prefetch(A);
 
   for (int n = 0; n < nsteps; n++) {
-    // consume the prefetched rows into window slots 4..6 (invalid cells become dem=+inf, w=0)
+    // consume the prefetched rows into window slots 4..6; the device DEM already holds +inf for
+    // NODATA cells, so only edge waves have anything to mask (cells outside the slab: dem=+inf, w=0)
 #pragma unroll
     for (int i = 0; i < 3; i++)
 #pragma unroll
       for (int j = 0; j < 3; j++) {
-        const bool ok = nrow_ok[i] & colok[j];
-        W[4 + i][j] = ok ? NW[i][j] : 0.0;
-        D[4 + i][j] = (ok & (ND[i][j] > g.miss)) ? ND[i][j] : WDPM_INF;
+        W[4 + i][j] = NW[i][j];
+        D[4 + i][j] = ND[i][j];
       }
+    if (edge) {
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        const bool row_ok = A + 3 * n + i < g.rows;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          const bool ok = row_ok & (colb + j < g.ncp);
+          W[4 + i][j] = ok ? W[4 + i][j] : 0.0;
+          D[4 + i][j] = ok ? D[4 + i][j] : WDPM_INF;
+        }
+      }
+    }
     if (n + 1 < nsteps) prefetch(A + 3 * (n + 1));
 
     const int rbase = A + 3 * n - 4;                 // slab row of window slot 0
@@ -242,17 +279,43 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
     stage<MODULE, SZ_SAFE, 2>(W, D, rbase + 2, g.dr, cdr, ds);   // oi = 2 on rows 3n-2 .. 3n
     stage<MODULE, SZ_SAFE, 0>(W, D, rbase + 0, g.dr, cdr, ds);   // oi = 3 on rows 3n-4 .. 3n-2
 
-    // rows 3n-4 .. 3n-2 have now seen all nine passes
+    // rows 3n-4 .. 3n-2 have now seen all nine passes.  A lane holds 3 adjacent columns, so storing
+    // straight from registers would be three 8-byte stores per row with a 24-byte lane stride:
+    // every store instruction touches all 12 cache lines of the segment with a third of their
+    // bytes, and the L2 write path (not HBM) becomes the bottleneck (measured: 27 % of the kernel).
+    // Instead the wave transposes each row through its private LDS slice — no barrier, a wave's
+    // LDS operations complete in order — and stores 512 contiguous bytes per instruction.
 #pragma unroll
     for (int i = 0; i < 3; i++) {
       const int r = rbase + i;
       if (r >= or_lo && r <= or_hi) {               // wave-uniform
-        const size_t rowoff = (size_t)r * g.ncp + colb;
 #pragma unroll
-        for (int j = 0; j < 3; j++)
-          if (stok[j]) wout[rowoff + j] = W[i][j];
+        for (int j = 0; j < 3; j++) stage_lds[i * kStripIn + 3 * lane + j] = W[i][j];
       }
     }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const int r = rbase + i;
+      if (r >= or_lo && r <= or_hi) {
+#ifdef WDPM_ABLATE_STORE_REGION  /* timing experiment only: all writes land in 64 rows (stay in cache) */
+        double *const orow = wout + (size_t)(r & 63) * pitch + c0;
+#else
+        double *const orow = wout + (size_t)r * pitch + c0;
+#endif
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          const double v = stage_lds[i * kStripIn + 64 * k + lane];
+#ifdef WDPM_ABLATE_STORES      /* timing experiment only */
+          if (st_ok[k] && v == -123.456) orow[64 * k + lane] = v;
+#else
+          // streamed out: the line is not read again before 2 GB of other traffic has passed
+          if (st_ok[k]) __builtin_nontemporal_store(v, &orow[64 * k + lane]);
+#endif
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
     // slide the window down three rows
 #pragma unroll
     for (int k = 0; k < 4; k++)

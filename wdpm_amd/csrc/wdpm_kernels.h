@@ -19,6 +19,8 @@ struct SlabGeom {
   double miss;   /* NODATA value */
 };
 
+/* in place: dem <= miss (or NaN) -> +inf.  Every other kernel expects the DEM in this form. */
+hipError_t wdpm_launch_mark_nodata(double *dem, size_t cells, double miss, hipStream_t s);
 /* one colour pass, in place (reference kernels add/subtract/ddrain, runoff.cl:137-183) */
 hipError_t wdpm_launch_pass(int module, double *w, const double *dem, const SlabGeom &g, int oi, int oj,
                             double *totaldrain, hipStream_t s);

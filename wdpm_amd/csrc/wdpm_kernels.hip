@@ -12,6 +12,26 @@
 #include "wdpm_kernels.h"
 #include "wdpm_stencil.h"
 
+/* The device copy of the DEM holds +inf where bigdem <= missingvalue (wdpm_launch_mark_nodata), so
+ * "bigdem > missingvalue" (WDPMCL.c:1099,1944,1248,1880) is `dem < +inf` everywhere on the device. */
+__device__ __forceinline__ bool cell_valid(const double dem) { return dem < __builtin_inf(); }
+
+__global__ void __launch_bounds__(256)
+mark_nodata_kernel(double *__restrict__ dem, size_t cells, double miss) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += stride) {
+    const double d = dem[i];
+    if (!(d > miss)) dem[i] = __builtin_inf();
+  }
+}
+
+hipError_t wdpm_launch_mark_nodata(double *dem, size_t cells, double miss, hipStream_t s) {
+  size_t blocks = (cells + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(mark_nodata_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dem, cells, miss);
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------
 // one colour pass: one thread per 3x3 block of the pass, in place
 // ---------------------------------------------------------------------------------------------
@@ -27,7 +47,7 @@ pass_kernel(double *__restrict__ w, const double *__restrict__ dem, SlabGeom g, 
   const size_t ic = (size_t)r * g.ncp + c;
   const double dc_ = dem[ic];
   double wc = w[ic];
-  if (!(wc > 0.0 && dc_ > g.miss)) return;          // WDPMCL.c:1099
+  if (!(wc > 0.0 && cell_valid(dc_))) return;       // WDPMCL.c:1099
   if (MODULE == 2 && r == g.dr && c == g.dc) return; // WDPMCL.c:1082
   double td = 0.0;
   bool drained = false;
@@ -36,7 +56,7 @@ pass_kernel(double *__restrict__ w, const double *__restrict__ dem, SlabGeom g, 
     const int rr = r + nb_dr(k), cc = c + nb_dc(k);
     const size_t in = (size_t)rr * g.ncp + cc;
     const double dn = dem[in];
-    if (!(dn > g.miss)) continue;
+    if (!cell_valid(dn)) continue;
     double wn = w[in];
     if (MODULE == 2) {
       if (rr == g.dr && cc == g.dc) {
@@ -84,7 +104,7 @@ __global__ void drain_outlet_kernel(double *__restrict__ w, const double *__rest
     for (int j = -1; j <= 1; j++) {
       const size_t k = (size_t)(g.dr + i) * g.ncp + (g.dc + j);
       const double wk = w[k];
-      if (dem[k] > g.miss && wk > 0) s += wk;   // WDPMCL.c:1877-1884
+      if (cell_valid(dem[k]) && wk > 0) s += wk;   // WDPMCL.c:1877-1884
     }
   for (int i = -1; i <= 1; i++)
     for (int j = -1; j <= 1; j++) w[(size_t)(g.dr + i) * g.ncp + (g.dc + j)] = 0.0;  // :1885-1889
@@ -165,12 +185,12 @@ __device__ __forceinline__ double wave_max(double m) {
 
 __global__ void __launch_bounds__(256)
 max_diff_kernel(const double *__restrict__ w, const double *__restrict__ old, const double *__restrict__ dem,
-                size_t first, size_t last, double miss, int seed_cell0, unsigned long long *result_bits) {
+                size_t first, size_t last, int seed_cell0, unsigned long long *result_bits) {
   __shared__ double part[4];
   double m = 0.0;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = first + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < last; i += stride) {
-    if (dem[i] > miss || (seed_cell0 && i == 0)) {   // WDPMCL.c:1245 seeds with diff[0][0]
+    if (cell_valid(dem[i]) || (seed_cell0 && i == 0)) {   // WDPMCL.c:1245 seeds with diff[0][0]
       const double d = fabs(w[i] - old[i]);
       if (d > m) m = d;
     }
@@ -194,6 +214,6 @@ hipError_t wdpm_launch_max_diff(const double *w, const double *old, const double
   size_t blocks = (last - first + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(max_diff_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w, old, dem, first, last,
-                     g.miss, row_lo == 0 ? 1 : 0, result_bits);
+                     row_lo == 0 ? 1 : 0, result_bits);
   return hipGetLastError();
 }
