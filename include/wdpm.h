@@ -108,6 +108,10 @@ int wdpm_max_diff(wdpm_ctx *ctx, int32_t row_lo, int32_t row_hi, double *out);
  * cellarea); final_sum = sum of bigwater over bigdem>missing in row-major order (NOT yet times
  * cellarea), bit-identical to the reference's sequential summation. */
 int wdpm_drain_stats(wdpm_ctx *ctx, double *diffdrain, double *final_sum);
+/* the same row-major sum restricted to slab-local rows [row_lo,row_hi) and continued from `start`:
+ * rank g of a row-block decomposition passes the sum of ranks 0..g-1, so the chain reproduces
+ * the single-raster summation order exactly. */
+int wdpm_volume_partial(wdpm_ctx *ctx, int32_t row_lo, int32_t row_hi, double start, double *sum);
 /* convenience: begin_block + iterate(n_iter) + max_diff over the whole slab */
 int wdpm_run_block(wdpm_ctx *ctx, int32_t n_iter, double thres, double *max_diff);
 

@@ -14,19 +14,29 @@ def run(rank, world, port, libpath, case, outdir):
     import torch.distributed as dist
     import wdpm_amd
     from wdpm_amd.rowblock import HostTransport, RowBlockSolver
-    from helpers import pad, random_case
+    from helpers import find_drain, pad, random_case
 
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     lib = wdpm_amd.load(libpath)
     dem, water, miss = random_case(case["seed"], case["R"], case["C"])
     bd, bw = pad(dem, water, miss)
+    kw = dict(case.get("ctx_kw", {}))
+    drain = case["module"] == "drain"
+    if drain:
+        dr, dc = find_drain(bd)
+        kw.update(drainrow=dr, draincol=dc)
     s = RowBlockSolver(lib, case["module"], case["R"], case["C"], miss, rank=rank, nranks=world,
-                       exchange_every=case["k"], transport=HostTransport(dist), dist=dist,
-                       **case.get("ctx_kw", {}))
+                       exchange_every=case["k"], transport=HostTransport(dist), dist=dist, **kw)
     s.upload_global(bd, bw)
-    mds = [s.run_block(n, case["thres"]) for n in case["blocks"]]
+    if drain:
+        s.set_totaldrain(max(bw[dr, dc], 0.0))
+    mds, stats = [], []
+    for n in case["blocks"]:
+        mds.append(s.run_block(n, case["thres"]))
+        if drain:
+            stats.append(list(s.drain_stats()) + [s.totaldrain()])
     np.savez(os.path.join(outdir, f"rank{rank}.npz"), own=s.owned_water(), lo=s.slab.own_lo, hi=s.slab.own_hi,
-             mds=np.array(mds))
+             mds=np.array(mds), stats=np.array(stats))
     s.close()
     dist.barrier()
     dist.destroy_process_group()

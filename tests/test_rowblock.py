@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 from conftest import ORACLE_SO, ROOT
-from helpers import bits_equal, n_bit_diff, pad, random_case
+from helpers import bits_equal, find_drain, n_bit_diff, pad, random_case
 from wdpm_amd.rowblock import RowBlockSolver, halo_depth, partition
 
 
@@ -36,11 +36,22 @@ def run_ranks(world, case, libpath=ORACLE_SO, env=None):
 def single(oracle, case):
     dem, water, miss = random_case(case["seed"], case["R"], case["C"])
     bd, bw = pad(dem, water, miss)
-    s = RowBlockSolver(oracle, case["module"], case["R"], case["C"], miss)
+    kw = {}
+    if case["module"] == "drain":
+        dr, dc = find_drain(bd)
+        kw = dict(drainrow=dr, draincol=dc)
+    s = RowBlockSolver(oracle, case["module"], case["R"], case["C"], miss, **kw)
     s.upload_global(bd, bw)
-    mds = [s.run_block(n, case["thres"]) for n in case["blocks"]]
+    if kw:
+        s.set_totaldrain(max(bw[dr, dc], 0.0))
+    mds, stats = [], []
+    for n in case["blocks"]:
+        mds.append(s.run_block(n, case["thres"]))
+        if kw:
+            stats.append(list(s.drain_stats()) + [s.totaldrain()])
     w = s.ctx.download_water()
     s.close()
+    case["_stats"] = stats
     return w, mds
 
 
@@ -72,6 +83,22 @@ def test_multirank_equals_single_slab(oracle, world, k):
         lo, hi = int(g["lo"]), int(g["hi"])
         assert bits_equal(g["own"], want[lo:hi + 1]), f"rows {lo}..{hi}: {n_bit_diff(g['own'], want[lo:hi + 1])} cells differ"
         assert list(g["mds"]) == mds
+
+
+@pytest.mark.parametrize("world,k,R", [(2, 2, 150), (3, 1, 210)])
+def test_multirank_drain_equals_single_slab(oracle, world, k, R):
+    """drain module across ranks: water, max diff, totaldrain, |d totaldrain| and the chained
+    row-major volume sum all equal the single-slab values bit for bit"""
+    case = dict(seed=17, R=R, C=61, module="drain", k=k, thres=0.005 / 1000, blocks=[9, 6])
+    want, mds = single(oracle, case)
+    stats = case.pop("_stats")
+    got = run_ranks(world, case)
+    for g in got:
+        lo, hi = int(g["lo"]), int(g["hi"])
+        assert bits_equal(g["own"], want[lo:hi + 1])
+        assert list(g["mds"]) == mds
+        assert g["stats"].tolist() == stats
+    assert stats[0][2] > 0      # something was drained, so the test is not vacuous
 
 
 def test_halo_depth_is_sufficient(oracle):
@@ -114,3 +141,18 @@ def test_multirank_hip_slabs_over_gloo(oracle, hip, world, k):
         lo, hi = int(g["lo"]), int(g["hi"])
         assert bits_equal(g["own"], want[lo:hi + 1]), f"rows {lo}..{hi}: {n_bit_diff(g['own'], want[lo:hi + 1])} cells differ"
         assert list(g["mds"]) == mds
+
+
+@pytest.mark.gpu
+def test_multirank_hip_drain_over_gloo(oracle, hip):
+    case = dict(seed=18, R=240, C=380, module="drain", k=2, thres=0.005 / 1000, blocks=[9, 6], ctx_kw=dict(device=0))
+    want, mds = single(oracle, dict(case, ctx_kw={}))
+    ref = dict(case, ctx_kw={})
+    single(oracle, ref)
+    stats = ref["_stats"]
+    got = run_ranks(2, case, libpath=hip.path)
+    for g in got:
+        lo, hi = int(g["lo"]), int(g["hi"])
+        assert bits_equal(g["own"], want[lo:hi + 1])
+        assert list(g["mds"]) == mds
+        assert g["stats"].tolist() == stats

@@ -56,6 +56,7 @@ SYMBOLS = {
     "wdpm_drain_outlet": (C.c_int, [_vp]),
     "wdpm_max_diff": (C.c_int, [_vp, C.c_int32, C.c_int32, _dp]),
     "wdpm_drain_stats": (C.c_int, [_vp, _dp, _dp]),
+    "wdpm_volume_partial": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_double, _dp]),
     "wdpm_run_block": (C.c_int, [_vp, C.c_int32, C.c_double, _dp]),
     "wdpm_water_ptr": (C.c_int, [_vp, C.POINTER(_vp)]),
     "wdpm_dem_ptr": (C.c_int, [_vp, C.POINTER(_vp)]),
@@ -241,10 +242,21 @@ class Context:
         self.lib.check(self.lib.dll.wdpm_max_diff(self._h, row_lo, hi, C.byref(v)))
         return v.value
 
+    def drain_stats_diff(self) -> float:
+        """|totaldrain - olddrain| only (no raster download)"""
+        a = C.c_double()
+        self.lib.check(self.lib.dll.wdpm_drain_stats(self._h, C.byref(a), None))
+        return a.value
+
     def drain_stats(self):
         a, b = C.c_double(), C.c_double()
         self.lib.check(self.lib.dll.wdpm_drain_stats(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def volume_partial(self, row_lo: int, row_hi: int, start: float = 0.0) -> float:
+        v = C.c_double()
+        self.lib.check(self.lib.dll.wdpm_volume_partial(self._h, row_lo, row_hi, start, C.byref(v)))
+        return v.value
 
     def run_block(self, n_iter: int, thres: float) -> float:
         v = C.c_double()

@@ -335,16 +335,24 @@ int wdpm_drain_stats(wdpm_ctx *x, double *diffdrain, double *final_sum) {
     HIP_TRY(hipStreamSynchronize(x->stream));
     *diffdrain = fabs(x->h_pin[0] - x->h_pin[1]);
   }
-  if (final_sum) {
-    if (x->h_valid.size() != x->cells) return fail("wdpm_drain_stats: no DEM has been uploaded to this drain context");
-    std::vector<double> w(x->cells);
-    HIP_TRY(hipMemcpyAsync(w.data(), x->d_w[x->cur], x->cells * sizeof(double), hipMemcpyDeviceToHost, x->stream));
+  if (final_sum) return wdpm_volume_partial(x, 0, x->g.rows, 0.0, final_sum);
+  return 0;
+}
+
+int wdpm_volume_partial(wdpm_ctx *x, int32_t row_lo, int32_t row_hi, double start, double *sum) {
+  if (row_lo < 0 || row_hi > x->g.rows || row_lo > row_hi || !sum) return fail("wdpm_volume_partial: bad row range");
+  if (x->h_valid.size() != x->cells) return fail("wdpm_volume_partial: no DEM has been uploaded to this drain context");
+  if (bind(x)) return 1;
+  const size_t first = (size_t)row_lo * x->g.ncp, n = (size_t)(row_hi - row_lo) * x->g.ncp;
+  std::vector<double> w(n);
+  if (n) {
+    HIP_TRY(hipMemcpyAsync(w.data(), x->d_w[x->cur] + first, n * sizeof(double), hipMemcpyDeviceToHost, x->stream));
     HIP_TRY(hipStreamSynchronize(x->stream));
-    double s = 0;
-    for (size_t i = 0; i < x->cells; i++)
-      if (x->h_valid[i]) s += w[i];
-    *final_sum = s;
   }
+  double s = start;
+  for (size_t i = 0; i < n; i++)
+    if (x->h_valid[first + i]) s += w[i];
+  *sum = s;
   return 0;
 }
 

@@ -153,6 +153,8 @@ class RowBlockSolver:
                                slab_rows=s.rows if nranks > 1 else 0, **ctx_kw)
         self.module = self.ctx.module
         self._since_exchange = 0
+        # drain module: the rank whose OWNED rows hold the outlet has the raster's totaldrain
+        self.drain_owner = next((sl.rank for sl in self.slabs if sl.own_lo <= drainrow <= sl.own_hi), 0)
 
     def close(self):
         self.ctx.close()
@@ -234,3 +236,36 @@ class RowBlockSolver:
         self.begin_block(thres)
         self.iterate(n_iter)
         return self.max_diff()
+
+    # -- drain bookkeeping (WDPMCL.c:1257-1268) across ranks
+    def _bcast(self, values, src):
+        import torch
+        t = torch.tensor(values, dtype=torch.float64)
+        if self.dist.get_backend() == "nccl":
+            t = t.cuda()
+        self.dist.broadcast(t, src=src)
+        return [float(v) for v in t.cpu()]
+
+    def set_totaldrain(self, v: float):
+        self.ctx.totaldrain = v
+
+    def totaldrain(self) -> float:
+        td = self.ctx.totaldrain
+        return self._bcast([td], self.drain_owner)[0] if self.nranks > 1 else td
+
+    def drain_stats(self):
+        """(|totaldrain - olddrain|, sum of water over valid cells in the reference's row-major
+        order).  The sum is chained rank to rank so that its rounding equals the single-raster sum."""
+        if self.nranks == 1:
+            return self.ctx.drain_stats()
+        import torch
+        s, nccl = self.slab, self.dist.get_backend() == "nccl"
+        run = torch.zeros(1, dtype=torch.float64, device="cuda" if nccl else "cpu")
+        if s.rank > 0:
+            self.dist.recv(run, src=s.rank - 1)
+        part = self.ctx.volume_partial(s.lo, s.hi, float(run.item()))
+        if s.rank < s.nranks - 1:
+            self.dist.send(torch.tensor([part], dtype=torch.float64, device=run.device), dst=s.rank + 1)
+        final_sum = self._bcast([part], s.nranks - 1)[0]
+        diffdrain = self._bcast([self.ctx.drain_stats_diff()], self.drain_owner)[0]
+        return diffdrain, final_sum
