@@ -109,8 +109,9 @@ int wdpm_create(wdpm_ctx **out, const wdpm_params *p) {
   const size_t bytes = x->cells * sizeof(double);
   hipError_t e = hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipMalloc(&x->d_dem, bytes);
-  if (e == hipSuccess) e = hipMalloc(&x->d_w[0], bytes);
-  if (e == hipSuccess) e = hipMalloc(&x->d_w[1], bytes);
+  /* + 64 doubles behind each water raster: the fused kernel's dump area for masked-out stores */
+  if (e == hipSuccess) e = hipMalloc(&x->d_w[0], bytes + 64 * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(&x->d_w[1], bytes + 64 * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&x->d_old, bytes);
   if (e == hipSuccess) e = hipMalloc(&x->d_scal, 2 * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&x->d_bits, sizeof(unsigned long long));

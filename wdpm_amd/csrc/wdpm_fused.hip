@@ -31,6 +31,7 @@
 #include "wdpm_stencil.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -164,6 +165,9 @@ __device__ __forceinline__ void stage(double (&W)[7][3], const double (&D)[7][3]
   W[c][0] = lane_prev(wc0, W[c][0]);  W[c][1] = lane_prev(wc1, W[c][1]);
 }
 
+#ifndef WDPM_PREFETCH_DEPTH
+#define WDPM_PREFETCH_DEPTH 1   /* 2 measured slower (208 VGPRs, twice the loop code) */
+#endif
 #ifndef WDPM_FUSED_MIN_WAVES
 #define WDPM_FUSED_MIN_WAVES 2   /* waves per SIMD the register allocator must leave room for */
 #endif
@@ -174,7 +178,12 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
                        const double *__restrict__ dem, const SlabGeom g, const int nstrips,
                        const int nitems, const int H, double *__restrict__ totaldrain) {
   const int lane = threadIdx.x & 63;
-  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+  // Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2; placement is only a
+  // speed matter, never correctness): give each XCD a contiguous run of work items so that the
+  // halo columns shared by neighbouring strips hit in its L2 (+2 % measured).  gridDim.x is a
+  // multiple of 8, so b -> (b % 8) * (gridDim.x / 8) + b / 8 is a permutation of the blocks.
+  const int vb = (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8;
+  const int item = vb * 4 + (threadIdx.x >> 6);
   if (item >= nitems) return;                       // wave-uniform
   const int strip = item % nstrips, chunk = item / nstrips;
   const int c0 = kStripOut * strip;
@@ -210,118 +219,128 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
     for (int j = 0; j < 3; j++) { W[k][j] = 0.0; D[k][j] = WDPM_INF; }
 
   // Only waves of the last strip / last chunk can touch cells outside the slab; every other wave
-  // loads without any predicate.  `edge` is wave-uniform.
-  const bool edge = (c0 + kStripIn > g.ncp) || (A + 3 * nsteps > g.rows);
+  // loads without any predicate.  `edge` is wave-uniform (the margin lets interior waves prefetch
+  // past their last step unconditionally).
+  const bool edge = (c0 + kStripIn > g.ncp) || (A + 3 * (nsteps + WDPM_PREFETCH_DEPTH) > g.rows);
   const size_t pitch = (size_t)g.ncp;
-  // running pointers to the first of the three rows to prefetch next (interior waves only)
-  const double *pw = win + (size_t)A * pitch + (edge ? 0 : colb);
-  const double *pd = dem + (size_t)A * pitch + (edge ? 0 : colb);
-  int cclamp[3];                                               // edge waves: per-column clamped index
-#pragma unroll
-  for (int j = 0; j < 3; j++) cclamp[j] = colb + j < g.ncp ? colb + j : g.ncp - 1;
+  // Cells a wave must not write (outside its exact output block) are redirected to a 64-double
+  // dump area behind the raster instead of being branched around: the loop then issues the same
+  // number of loads and stores on every trip, so the compiler can wait with exact vmcnt counts
+  // (with conditional memory operations it falls back to vmcnt(0) at the top of each step, which
+  // exposes the full latency of the stores just issued — measured 27 % of the kernel).
+  double *const dump = wout + (size_t)g.rows * pitch + lane;
 
-  // raw prefetch registers for the next step's three rows
-  double NW[3][3], ND[3][3];
-  auto prefetch = [&](const int r0) {
-    if (!edge) {
+  // The marching loop, instantiated for interior (EDGE = false) and edge waves.
+  auto march = [&](auto edge_tag) {
+    constexpr bool EDGE = decltype(edge_tag)::value;
+    // running pointers to the first of the three rows to prefetch next (interior waves)
+    const double *pw = win + (size_t)A * pitch + (EDGE ? 0 : colb);
+    const double *pd = dem + (size_t)A * pitch + (EDGE ? 0 : colb);
+    int cclamp[3];                                             // edge waves: per-column clamped index
+#pragma unroll
+    for (int j = 0; j < 3; j++) cclamp[j] = colb + j < g.ncp ? colb + j : g.ncp - 1;
+
+    // raw prefetch registers: rows are requested WDPM_PREFETCH_DEPTH steps before they are used
+    auto prefetch = [&](double (&NW)[3][3], double (&ND)[3][3], const int r0) {
+      if (!EDGE) {
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+          for (int j = 0; j < 3; j++) {
+            NW[i][j] = pw[i * pitch + j];
+            ND[i][j] = pd[i * pitch + j];
+          }
+        pw += 3 * pitch;
+        pd += 3 * pitch;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          const int r = r0 + i < g.rows ? r0 + i : g.rows - 1;  // clamped, masked on use
+          const size_t off = (size_t)r * pitch;
+#pragma unroll
+          for (int j = 0; j < 3; j++) {
+            NW[i][j] = win[off + cclamp[j]];
+            ND[i][j] = dem[off + cclamp[j]];
+          }
+        }
+      }
+    };
+
+    auto step = [&](const int n, double (&NW)[3][3], double (&ND)[3][3]) {
+      // consume the prefetched rows into window slots 4..6; the device DEM already holds +inf for
+      // NODATA cells, so only edge waves have anything to mask (outside the slab: dem=+inf, w=0)
 #pragma unroll
       for (int i = 0; i < 3; i++)
 #pragma unroll
         for (int j = 0; j < 3; j++) {
-          NW[i][j] = pw[i * pitch + j];
-          ND[i][j] = pd[i * pitch + j];
+          W[4 + i][j] = NW[i][j];
+          D[4 + i][j] = ND[i][j];
         }
-#ifndef WDPM_ABLATE_LOADS   /* timing experiment only: re-read the same three rows (cache hits) */
-      pw += 3 * pitch;
-      pd += 3 * pitch;
-#endif
-    } else {
+      if (EDGE) {
 #pragma unroll
-      for (int i = 0; i < 3; i++) {
-        const int r = r0 + i < g.rows ? r0 + i : g.rows - 1;    // clamped, masked on use
-        const size_t off = (size_t)r * pitch;
+        for (int i = 0; i < 3; i++) {
+          const bool row_ok = A + 3 * n + i < g.rows;
 #pragma unroll
-        for (int j = 0; j < 3; j++) {
-          NW[i][j] = win[off + cclamp[j]];
-          ND[i][j] = dem[off + cclamp[j]];
+          for (int j = 0; j < 3; j++) {
+            const bool ok = row_ok & (colb + j < g.ncp);
+            W[4 + i][j] = ok ? W[4 + i][j] : 0.0;
+            D[4 + i][j] = ok ? D[4 + i][j] : WDPM_INF;
+          }
         }
       }
-    }
-  };
-  prefetch(A);
+      // always issued (the last trips re-read clamped / following rows and drop them)
+      prefetch(NW, ND, A + 3 * (n + WDPM_PREFETCH_DEPTH));
 
-  for (int n = 0; n < nsteps; n++) {
-    // consume the prefetched rows into window slots 4..6; the device DEM already holds +inf for
-    // NODATA cells, so only edge waves have anything to mask (cells outside the slab: dem=+inf, w=0)
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-      for (int j = 0; j < 3; j++) {
-        W[4 + i][j] = NW[i][j];
-        D[4 + i][j] = ND[i][j];
-      }
-    if (edge) {
-#pragma unroll
-      for (int i = 0; i < 3; i++) {
-        const bool row_ok = A + 3 * n + i < g.rows;
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-          const bool ok = row_ok & (colb + j < g.ncp);
-          W[4 + i][j] = ok ? W[4 + i][j] : 0.0;
-          D[4 + i][j] = ok ? D[4 + i][j] : WDPM_INF;
-        }
-      }
-    }
-    if (n + 1 < nsteps) prefetch(A + 3 * (n + 1));
+      const int rbase = A + 3 * n - 4;                 // slab row of window slot 0
+      stage<MODULE, SZ_SAFE, 4>(W, D, rbase + 4, g.dr, cdr, ds);   // oi = 1 on rows 3n   .. 3n+2
+      stage<MODULE, SZ_SAFE, 2>(W, D, rbase + 2, g.dr, cdr, ds);   // oi = 2 on rows 3n-2 .. 3n
+      stage<MODULE, SZ_SAFE, 0>(W, D, rbase + 0, g.dr, cdr, ds);   // oi = 3 on rows 3n-4 .. 3n-2
 
-    const int rbase = A + 3 * n - 4;                 // slab row of window slot 0
-    stage<MODULE, SZ_SAFE, 4>(W, D, rbase + 4, g.dr, cdr, ds);   // oi = 1 on rows 3n   .. 3n+2
-    stage<MODULE, SZ_SAFE, 2>(W, D, rbase + 2, g.dr, cdr, ds);   // oi = 2 on rows 3n-2 .. 3n
-    stage<MODULE, SZ_SAFE, 0>(W, D, rbase + 0, g.dr, cdr, ds);   // oi = 3 on rows 3n-4 .. 3n-2
-
-    // rows 3n-4 .. 3n-2 have now seen all nine passes.  A lane holds 3 adjacent columns, so storing
-    // straight from registers would be three 8-byte stores per row with a 24-byte lane stride:
-    // every store instruction touches all 12 cache lines of the segment with a third of their
-    // bytes, and the L2 write path (not HBM) becomes the bottleneck (measured: 27 % of the kernel).
-    // Instead the wave transposes each row through its private LDS slice — no barrier, a wave's
-    // LDS operations complete in order — and stores 512 contiguous bytes per instruction.
+      // rows 3n-4 .. 3n-2 have now seen all nine passes.  The wave transposes each row through its
+      // private LDS slice (no barrier: a wave's LDS operations complete in order) so that every
+      // store instruction writes 512 contiguous bytes, streamed past the L2 (non-temporal).
 #pragma unroll
-    for (int i = 0; i < 3; i++) {
-      const int r = rbase + i;
-      if (r >= or_lo && r <= or_hi) {               // wave-uniform
+      for (int i = 0; i < 3; i++)
 #pragma unroll
         for (int j = 0; j < 3; j++) stage_lds[i * kStripIn + 3 * lane + j] = W[i][j];
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int i = 0; i < 3; i++) {
-      const int r = rbase + i;
-      if (r >= or_lo && r <= or_hi) {
-#ifdef WDPM_ABLATE_STORE_REGION  /* timing experiment only: all writes land in 64 rows (stay in cache) */
-        double *const orow = wout + (size_t)(r & 63) * pitch + c0;
-#else
-        double *const orow = wout + (size_t)r * pitch + c0;
-#endif
+      for (int i = 0; i < 3; i++) {
+        const int r = rbase + i;
+        const bool row_ok = r >= or_lo && r <= or_hi;             // wave-uniform
+        double *const orow = wout + (size_t)(row_ok ? r : 0) * pitch + c0 + lane;
 #pragma unroll
         for (int k = 0; k < 3; k++) {
           const double v = stage_lds[i * kStripIn + 64 * k + lane];
-#ifdef WDPM_ABLATE_STORES      /* timing experiment only */
-          if (st_ok[k] && v == -123.456) orow[64 * k + lane] = v;
-#else
-          // streamed out: the line is not read again before 2 GB of other traffic has passed
-          if (st_ok[k]) __builtin_nontemporal_store(v, &orow[64 * k + lane]);
-#endif
+          double *const dst = (row_ok && st_ok[k]) ? orow + 64 * k : dump;
+          __builtin_nontemporal_store(v, dst);
         }
       }
+      __builtin_amdgcn_wave_barrier();
+      // slide the window down three rows
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) { W[k][j] = W[k + 3][j]; D[k][j] = D[k + 3][j]; }
+    };
+
+#if WDPM_PREFETCH_DEPTH == 1
+    double NW0[3][3], ND0[3][3];
+    prefetch(NW0, ND0, A);
+    for (int n = 0; n < nsteps; n++) step(n, NW0, ND0);
+#else
+    // two register sets alternate: a row's loads are issued two steps before they are consumed
+    double NW0[3][3], ND0[3][3], NW1[3][3], ND1[3][3];
+    prefetch(NW0, ND0, A);
+    prefetch(NW1, ND1, A + 3);
+    for (int n = 0; n < nsteps; n += 2) {
+      step(n, NW0, ND0);
+      if (n + 1 < nsteps) step(n + 1, NW1, ND1);
     }
-    __builtin_amdgcn_wave_barrier();
-    // slide the window down three rows
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-#pragma unroll
-      for (int j = 0; j < 3; j++) { W[k][j] = W[k + 3][j]; D[k][j] = D[k + 3][j]; }
-  }
+#endif
+  };
+  if (edge) march(std::true_type{});
+  else march(std::false_type{});
 
   if (MODULE == 2) {
     // exactly one wave owns the outlet cell in its exact output region; it saw every pass that
@@ -416,7 +435,7 @@ hipError_t wdpm_launch_fused(int module, const double *w_in, double *w_out, cons
   int nchunks = (g.rows - 2 + H - 1) / H;
   if (nchunks < 1) nchunks = 1;
   const int nitems = nstrips * nchunks;
-  const dim3 grid((nitems + 3) / 4), block(256);
+  const dim3 grid(((nitems + 3) / 4 + 7) / 8 * 8), block(256);   // multiple of 8: see the XCD remap
   if (module == 2)
     hipLaunchKernelGGL((fused_iteration_kernel<2, true>), grid, block, 0, s, w_in, w_out, dem, g, nstrips, nitems, H, totaldrain);
   else if (fast)
