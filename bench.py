@@ -40,7 +40,23 @@ def build_slab_inputs(lib, n, slab):
     return bd, bw
 
 
-def cpu_baseline(n=1024, iters=12):
+def measured_traffic(n, world, kernel):
+    """HBM bytes per fused-kernel launch from the committed rocprofv3 PMC passes (separate
+    --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command, gfx950 x2 FETCH correction,
+    calibrated on kernels of known byte count: profiles/).  Only for the configuration they
+    were taken on; otherwise null."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        if t["size"] == n and t["n_gpus"] == world and kernel in ("auto", "fused"):
+            return t["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
+def cpu_baseline(n=4096, iters=24):
     """The CPU oracle (bit-equal port of the reference's serial path) timed on one host core on a
     bounded sample of the same workload.  A reported baseline, never the product path."""
     import subprocess
@@ -145,7 +161,8 @@ def main():
                        "exchange_every": args.exchange_every if world > 1 else None,
                        "max_diff_m": max_diff},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n, world, args.kernel),
+                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_CELL_UPDATE * own_cells,
                          "kernel_ms_per_iteration": iter_ms, "launches": launches,
                          "job_frac": value * ALGO_BYTES_PER_CELL_UPDATE / 1e9 / (HBM_PEAK_GBS * world)},
         }

@@ -165,9 +165,6 @@ __device__ __forceinline__ void stage(double (&W)[7][3], const double (&D)[7][3]
   W[c][0] = lane_prev(wc0, W[c][0]);  W[c][1] = lane_prev(wc1, W[c][1]);
 }
 
-#ifndef WDPM_PREFETCH_DEPTH
-#define WDPM_PREFETCH_DEPTH 1   /* 2 measured slower (208 VGPRs, twice the loop code) */
-#endif
 #ifndef WDPM_FUSED_MIN_WAVES
 #define WDPM_FUSED_MIN_WAVES 2   /* waves per SIMD the register allocator must leave room for */
 #endif
@@ -183,7 +180,10 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
   // halo columns shared by neighbouring strips hit in its L2 (+2 % measured).  gridDim.x is a
   // multiple of 8, so b -> (b % 8) * (gridDim.x / 8) + b / 8 is a permutation of the blocks.
   const int vb = (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8;
-  const int item = vb * 4 + (threadIdx.x >> 6);
+  // the wave number is the same in all 64 lanes: say so, and everything derived from it (strip,
+  // chunk, row bases, loop bounds) lives in SGPRs and is computed on the scalar unit
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int item = vb * 4 + wave;
   if (item >= nitems) return;                       // wave-uniform
   const int strip = item % nstrips, chunk = item / nstrips;
   const int c0 = kStripOut * strip;
@@ -196,15 +196,20 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
   if (or_hi > g.rows - 1) or_hi = g.rows - 1;
 
   const int colb = c0 + 3 * lane;
-  // store side: after the LDS transpose lane l holds columns c0 + l + 64k, k = 0,1,2
-  bool st_ok[3];
+  // store side: after the LDS transpose, store instruction k = 0,1,2 writes the strip-relative
+  // columns lo + 64k + lane of the exact output range [lo, hi].  Lanes past hi are clamped to hi:
+  // they read the same LDS word and write the same address with the same value as the last valid
+  // lane, so every store is unconditional (fixed instruction count) and nothing is written twice
+  // with different data.
+  int scol[3];
+  {
+    const int lo = oc_lo - c0;
+    const int hi = (oc_hi < g.ncp - 1 ? oc_hi : g.ncp - 1) - c0;
 #pragma unroll
-  for (int k = 0; k < 3; k++) {
-    const int col = c0 + 64 * k + lane;
-    st_ok[k] = col < g.ncp && col >= oc_lo && col <= oc_hi;
+    for (int k = 0; k < 3; k++) scol[k] = lo + 64 * k + lane < hi ? lo + 64 * k + lane : hi;
   }
   __shared__ double stage_all[4][3 * kStripIn];          // 4.5 KiB per wave, private to the wave
-  double *const stage_lds = stage_all[threadIdx.x >> 6];
+  double *const stage_lds = stage_all[wave];
   bool cdr[5];
 #pragma unroll
   for (int j = 0; j < 5; j++) cdr[j] = MODULE == 2 && colb + j == g.dc;
@@ -221,50 +226,63 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
   // Only waves of the last strip / last chunk can touch cells outside the slab; every other wave
   // loads without any predicate.  `edge` is wave-uniform (the margin lets interior waves prefetch
   // past their last step unconditionally).
-  const bool edge = (c0 + kStripIn > g.ncp) || (A + 3 * (nsteps + WDPM_PREFETCH_DEPTH) > g.rows);
+  const bool edge = (c0 + kStripIn > g.ncp) || (A + 3 * (nsteps + 1) > g.rows);
   const size_t pitch = (size_t)g.ncp;
   // Cells a wave must not write (outside its exact output block) are redirected to a 64-double
   // dump area behind the raster instead of being branched around: the loop then issues the same
   // number of loads and stores on every trip, so the compiler can wait with exact vmcnt counts
   // (with conditional memory operations it falls back to vmcnt(0) at the top of each step, which
   // exposes the full latency of the stores just issued — measured 27 % of the kernel).
-  double *const dump = wout + (size_t)g.rows * pitch + lane;
+  double *const dump = wout + (size_t)g.rows * pitch + lane;   // 64 doubles, allocated by wdpm_create
 
   // The marching loop, instantiated for interior (EDGE = false) and edge waves.
   auto march = [&](auto edge_tag) {
     constexpr bool EDGE = decltype(edge_tag)::value;
-    // running pointers to the first of the three rows to prefetch next (interior waves)
-    const double *pw = win + (size_t)A * pitch + (EDGE ? 0 : colb);
-    const double *pd = dem + (size_t)A * pitch + (EDGE ? 0 : colb);
-    int cclamp[3];                                             // edge waves: per-column clamped index
+    // lane byte offsets inside a row: interior waves use one offset + immediates, edge waves clamp
+    // every column into the raster (values of clamped cells are masked on use)
+    int voff[3];
 #pragma unroll
-    for (int j = 0; j < 3; j++) cclamp[j] = colb + j < g.ncp ? colb + j : g.ncp - 1;
+    for (int j = 0; j < 3; j++) voff[j] = 8 * (EDGE ? (colb + j < g.ncp ? colb + j : g.ncp - 1) : colb);
 
-    // raw prefetch registers: rows are requested WDPM_PREFETCH_DEPTH steps before they are used
+    // Prefetch of the three rows starting at r0 into raw registers.  The loads are issued with
+    // inline asm (saddr form: wave-uniform row base in SGPRs + a per-lane byte offset) so that
+    // they stay exactly here, one whole step ahead of their use, and are waited for with an exact
+    // `s_waitcnt vmcnt(9)` (the 9 stores of the step are the only younger memory operations).
+    // Left to the compiler the loads get sunk next to their consumer or guarded by vmcnt(0), which
+    // exposes a full memory round trip per step.  The registers are not read before wait_rows().
     auto prefetch = [&](double (&NW)[3][3], double (&ND)[3][3], const int r0) {
-      if (!EDGE) {
 #pragma unroll
-        for (int i = 0; i < 3; i++)
+      for (int i = 0; i < 3; i++) {
+        int r = r0 + i;
+        if (EDGE) r = r < g.rows ? r : g.rows - 1;
+        const double *bw = win + (size_t)r * pitch;     // wave-uniform
+        const double *bd = dem + (size_t)r * pitch;
+        if (!EDGE) {
+          asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(NW[i][0]) : "v"(voff[0]), "s"(bw) : "memory");
+          asm volatile("global_load_dwordx2 %0, %1, %2 offset:8" : "=v"(NW[i][1]) : "v"(voff[0]), "s"(bw) : "memory");
+          asm volatile("global_load_dwordx2 %0, %1, %2 offset:16" : "=v"(NW[i][2]) : "v"(voff[0]), "s"(bw) : "memory");
+          asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(ND[i][0]) : "v"(voff[0]), "s"(bd) : "memory");
+          asm volatile("global_load_dwordx2 %0, %1, %2 offset:8" : "=v"(ND[i][1]) : "v"(voff[0]), "s"(bd) : "memory");
+          asm volatile("global_load_dwordx2 %0, %1, %2 offset:16" : "=v"(ND[i][2]) : "v"(voff[0]), "s"(bd) : "memory");
+        } else {
 #pragma unroll
           for (int j = 0; j < 3; j++) {
-            NW[i][j] = pw[i * pitch + j];
-            ND[i][j] = pd[i * pitch + j];
-          }
-        pw += 3 * pitch;
-        pd += 3 * pitch;
-      } else {
-#pragma unroll
-        for (int i = 0; i < 3; i++) {
-          const int r = r0 + i < g.rows ? r0 + i : g.rows - 1;  // clamped, masked on use
-          const size_t off = (size_t)r * pitch;
-#pragma unroll
-          for (int j = 0; j < 3; j++) {
-            NW[i][j] = win[off + cclamp[j]];
-            ND[i][j] = dem[off + cclamp[j]];
+            asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(NW[i][j]) : "v"(voff[j]), "s"(bw) : "memory");
+            asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(ND[i][j]) : "v"(voff[j]), "s"(bd) : "memory");
           }
         }
       }
     };
+    // the wait that makes the prefetched registers readable; every register is an in/out operand so
+    // no use can be scheduled above it.  YOUNGER = memory operations issued after the loads.
+#define WDPM_WAIT_ROWS(YOUNGER)                                                                        \
+  asm volatile("s_waitcnt vmcnt(" #YOUNGER ")"                                                         \
+               : "+v"(NW[0][0]), "+v"(NW[0][1]), "+v"(NW[0][2]), "+v"(NW[1][0]), "+v"(NW[1][1]),       \
+                 "+v"(NW[1][2]), "+v"(NW[2][0]), "+v"(NW[2][1]), "+v"(NW[2][2]), "+v"(ND[0][0]),       \
+                 "+v"(ND[0][1]), "+v"(ND[0][2]), "+v"(ND[1][0]), "+v"(ND[1][1]), "+v"(ND[1][2]),       \
+                 "+v"(ND[2][0]), "+v"(ND[2][1]), "+v"(ND[2][2])                                        \
+               :                                                                                       \
+               : "memory")
 
     auto step = [&](const int n, double (&NW)[3][3], double (&ND)[3][3]) {
       // consume the prefetched rows into window slots 4..6; the device DEM already holds +inf for
@@ -289,7 +307,7 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
         }
       }
       // always issued (the last trips re-read clamped / following rows and drop them)
-      prefetch(NW, ND, A + 3 * (n + WDPM_PREFETCH_DEPTH));
+      prefetch(NW, ND, A + 3 * (n + 1));
 
       const int rbase = A + 3 * n - 4;                 // slab row of window slot 0
       stage<MODULE, SZ_SAFE, 4>(W, D, rbase + 4, g.dr, cdr, ds);   // oi = 1 on rows 3n   .. 3n+2
@@ -308,15 +326,19 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
       for (int i = 0; i < 3; i++) {
         const int r = rbase + i;
         const bool row_ok = r >= or_lo && r <= or_hi;             // wave-uniform
-        double *const orow = wout + (size_t)(row_ok ? r : 0) * pitch + c0 + lane;
+        // rows outside the chunk's output range (first / last trips only) go to the dump area
+        double *const orow = wout + (size_t)(row_ok ? r : 0) * pitch + c0;
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-          const double v = stage_lds[i * kStripIn + 64 * k + lane];
-          double *const dst = (row_ok && st_ok[k]) ? orow + 64 * k : dump;
-          __builtin_nontemporal_store(v, dst);
+          const double v = stage_lds[i * kStripIn + scol[k]];
+          __builtin_nontemporal_store(v, row_ok ? orow + scol[k] : dump);
         }
       }
       __builtin_amdgcn_wave_barrier();
+      // The rows requested at the top of this step must have landed before the compiler may touch
+      // their registers (it copies them around the loop back-edge): wait here, where the only
+      // younger memory operations are this step's 9 stores.
+      WDPM_WAIT_ROWS(9);
       // slide the window down three rows
 #pragma unroll
       for (int k = 0; k < 4; k++)
@@ -324,20 +346,11 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
         for (int j = 0; j < 3; j++) { W[k][j] = W[k + 3][j]; D[k][j] = D[k + 3][j]; }
     };
 
-#if WDPM_PREFETCH_DEPTH == 1
-    double NW0[3][3], ND0[3][3];
-    prefetch(NW0, ND0, A);
-    for (int n = 0; n < nsteps; n++) step(n, NW0, ND0);
-#else
-    // two register sets alternate: a row's loads are issued two steps before they are consumed
-    double NW0[3][3], ND0[3][3], NW1[3][3], ND1[3][3];
-    prefetch(NW0, ND0, A);
-    prefetch(NW1, ND1, A + 3);
-    for (int n = 0; n < nsteps; n += 2) {
-      step(n, NW0, ND0);
-      if (n + 1 < nsteps) step(n + 1, NW1, ND1);
-    }
-#endif
+    double NW[3][3], ND[3][3];
+    prefetch(NW, ND, A);
+    WDPM_WAIT_ROWS(0);
+    for (int n = 0; n < nsteps; n++) step(n, NW, ND);
+#undef WDPM_WAIT_ROWS
   };
   if (edge) march(std::true_type{});
   else march(std::false_type{});
