@@ -87,6 +87,9 @@ def main():
     ap.add_argument("--size", type=int, default=16384)
     ap.add_argument("--exchange-every", type=int, default=int(os.environ.get("WDPM_EXCHANGE_EVERY", "4")))
     ap.add_argument("--kernel", choices=["auto", "pass", "fused"], default="auto")
+    ap.add_argument("--module", choices=["add", "drain"], default="add",
+                    help="drain = BASELINE config 5: water-in is the add-100-mm state after --drain-spinup iterations")
+    ap.add_argument("--drain-spinup", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -117,12 +120,39 @@ def main():
         # escape hatch: stage halo rows through host memory over a gloo group
         from wdpm_amd.rowblock import HostTransport
         transport = HostTransport(dist, dist.new_group(backend="gloo"))
+    drain_kw = {}
+    if args.module == "drain":
+        # the outlet is the first row-major minimum of the DEM (WDPMCL.c:1005-1017), padded coordinates
+        full = lib.synth_dem(n, n)
+        k = int(np.argmin(full))
+        drain_kw = dict(drainrow=k // n + 1, draincol=k % n + 1)
+        del full
     solver = RowBlockSolver(lib, "add", n, n, MISSING, rank=rank, nranks=world, exchange_every=args.exchange_every,
                             transport=transport, dist=dist, device=local_rank, kernel=kernel)
     solver.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     bd, bw = build_slab_inputs(lib, n, solver.slab)
     solver.ctx.upload(bd, bw)
     solver.agree_on_options()
+    if args.module == "drain":
+        # spin the water up with the add module, then hand the state to a drain solver
+        solver.run_block(args.drain_spinup, THRES)
+        solver.exchange()
+        bw = solver.ctx.download_water()
+        solver.close()
+        solver = RowBlockSolver(lib, "drain", n, n, MISSING, rank=rank, nranks=world,
+                                exchange_every=args.exchange_every, transport=transport, dist=dist,
+                                device=local_rank, kernel=kernel, **drain_kw)
+        solver.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        solver.ctx.upload(bd, bw)
+        solver.agree_on_options()
+        s = solver.slab
+        dr = drain_kw["drainrow"]
+        w_out = float(bw[dr - s.row0, drain_kw["draincol"]]) if s.row0 <= dr < s.row0 + s.rows else 0.0
+        if world > 1:
+            t = torch.tensor([w_out], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            w_out = float(t.item())
+        solver.set_totaldrain(max(w_out, 0.0))
     del bd, bw
 
     def sync():
@@ -151,12 +181,15 @@ def main():
         iter_ms = kernel_ms / max(args.steps, 1)     # device time of one iteration's stencil launch(es)
         achieved = ALGO_BYTES_PER_CELL_UPDATE * own_cells / (iter_ms * 1e-3) / 1e9 if iter_ms > 0 else 0.0
         out = {
-            "metric": "cell-updates/sec on Add module, 16k x 16k DEM",
+            "metric": "cell-updates/sec on Add module, 16k x 16k DEM" if args.module == "add" else
+                      "cell-updates/sec on Drain module (BASELINE config 5)",
             "value": value, "unit": "cell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"synthetic {n}x{n} diamond-square DEM (seed {n}), Add 100 mm, rof 1.0, "
-                                   f"thres 0.005 mm, one block of {args.steps} iterations",
+            "config": {"workload": (f"synthetic {n}x{n} diamond-square DEM (seed {n}), Add 100 mm, rof 1.0, "
+                                    f"thres 0.005 mm, one block of {args.steps} iterations") if args.module == "add" else
+                                   (f"synthetic {n}x{n} DEM (seed {n}), Drain from the add-100-mm state after "
+                                    f"{args.drain_spinup} iterations, one block of {args.steps} iterations"),
                        "kernel": args.kernel, "decomposition": f"row-block x{world}" if world > 1 else "single GPU",
                        "exchange_every": args.exchange_every if world > 1 else None,
                        "max_diff_m": max_diff},

@@ -225,3 +225,26 @@ def test_negative_and_nan_inputs_are_handled_like_the_reference(hip, oracle):
         g.iterate(5)
         o.iterate(5)
         assert bits_equal(g.download_water(), o.download_water())
+
+
+def test_synthetic_1024_drain_matches_oracle(hip, oracle):
+    """BASELINE config 5 at the reduced size SURVEY §8d names (1024^2): drain from the add-100-mm state,
+    totaldrain / vol change / water left and the raster equal the CPU oracle bit for bit"""
+    n, miss = 1024, -99999.0
+    dem = hip.synth_dem(n, n)
+    bd, bw = pad(dem, np.full((n, n), 0.1), miss)
+    with hip.context(module="add", nrows=n, ncols=n, missingvalue=miss) as a:
+        a.upload(bd, bw)
+        a.run_block(200, 0.005 / 1000)
+        w0 = a.download_water()
+    dr, dc = find_drain(bd)
+    kw = dict(module="drain", nrows=n, ncols=n, missingvalue=miss, drainrow=dr, draincol=dc)
+    with hip.context(**kw) as g, oracle.context(**kw) as o:
+        for c in (g, o):
+            c.upload(bd, w0)
+            c.totaldrain = max(w0[dr, dc], 0.0)
+        mg, mo = g.run_block(40, 0.005 / 1000), o.run_block(40, 0.005 / 1000)
+        assert mg == mo
+        assert n_bit_diff(g.download_water(), o.download_water()) == 0
+        assert g.totaldrain == o.totaldrain and g.totaldrain > 0
+        assert g.drain_stats() == o.drain_stats()

@@ -9,9 +9,109 @@
 #include "arcascii.h"
 
 #include <ctype.h>
+#include <pthread.h>
+#include <unistd.h>
+#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+
+/* ---- exact fast paths ------------------------------------------------------------------------
+ * asc_format_f6: what snprintf(buf, n, "%f", x) writes, without the trailing NUL: the exact binary
+ * value rounded to 6 decimals, ties to even (glibc in the default rounding mode).  Pure integer
+ * arithmetic on the IEEE-754 fields; anything unusual (NaN, inf, |x| >= 2^63) goes to snprintf.
+ * asc_parse_double: strtod for the plain decimal form [+-]digits[.digits][e[+-]digits] when the
+ * result is exact by Clinger's fast path (<= 15 significant digits, |power of ten| <= 22: one
+ * correctly rounded multiply or divide of two exact doubles); everything else goes to strtod. */
+int asc_format_f6(double x, char *out) {
+  uint64_t bits;
+  memcpy(&bits, &x, sizeof bits);
+  const int neg = (int)(bits >> 63);
+  const int e = (int)((bits >> 52) & 0x7FF);
+  uint64_t m = bits & 0xFFFFFFFFFFFFFull;
+  if (e == 0x7FF || e >= 1023 + 63) return sprintf(out, "%f", x);
+  uint64_t ip, q;
+  if (e == 0 && m == 0) {
+    ip = 0; q = 0;
+  } else {
+    int sh;                         /* value = m * 2^-sh */
+    if (e == 0) sh = 1074; else { m |= 1ull << 52; sh = 1075 - e; }
+    if (sh <= 0) { ip = m << (-sh); q = 0; }
+    else if (sh >= 75) { ip = 0; q = 0; }                 /* < 2^-22: rounds to 0.000000 */
+    else {
+      uint64_t fr;
+      if (sh >= 64) { ip = 0; fr = m; } else { ip = m >> sh; fr = m & ((1ull << sh) - 1); }
+      const unsigned __int128 num = (unsigned __int128)fr * 1000000u;
+      const unsigned __int128 one = (unsigned __int128)1 << sh;
+      q = (uint64_t)(num >> sh);
+      const unsigned __int128 rem = num & (one - 1), half = one >> 1;
+      if (rem > half || (rem == half && (q & 1))) q++;
+      if (q == 1000000u) { q = 0; ip++; }
+    }
+  }
+  int n = 0;
+  if (neg) out[n++] = '-';
+  if (ip < 10) {
+    out[n++] = (char)('0' + ip);
+  } else if (ip < 10000) {               /* the usual case: depths and elevations in metres */
+    const unsigned v = (unsigned)ip;
+    if (v >= 1000) out[n++] = (char)('0' + v / 1000);
+    if (v >= 100) out[n++] = (char)('0' + v / 100 % 10);
+    out[n++] = (char)('0' + v / 10 % 10);
+    out[n++] = (char)('0' + v % 10);
+  } else {
+    char tmp[24];
+    int k = 0;
+    do { tmp[k++] = (char)('0' + ip % 10); ip /= 10; } while (ip);
+    while (k) out[n++] = tmp[--k];
+  }
+  out[n++] = '.';
+  const unsigned qq = (unsigned)q, hi = qq / 1000, lo = qq % 1000;
+  out[n + 0] = (char)('0' + hi / 100); out[n + 1] = (char)('0' + hi / 10 % 10); out[n + 2] = (char)('0' + hi % 10);
+  out[n + 3] = (char)('0' + lo / 100); out[n + 4] = (char)('0' + lo / 10 % 10); out[n + 5] = (char)('0' + lo % 10);
+  return n + 6;
+}
+
+static const double kPow10[23] = {1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7,  1e8,  1e9,  1e10, 1e11,
+                                  1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+
+double asc_parse_double(const char *p, char **end) {
+  const char *s = p;
+  while (*s == ' ' || *s == '\n' || *s == '\t' || *s == '\r' || *s == '\f' || *s == '\v') s++;
+  const char *start = s;
+  int neg = 0;
+  if (*s == '-') { neg = 1; s++; } else if (*s == '+') s++;
+  uint64_t w = 0;
+  int nd = 0, dropped = 0, exp10 = 0, any = 0;
+  for (; *s >= '0' && *s <= '9'; s++) {
+    any = 1;
+    if (nd < 19) { if (w || *s != '0') { w = w * 10 + (uint64_t)(*s - '0'); nd++; } }
+    else dropped = 1, exp10++;
+  }
+  if (*s == '.') {
+    s++;
+    for (; *s >= '0' && *s <= '9'; s++) {
+      any = 1;
+      if (nd < 19) { if (w || *s != '0') { w = w * 10 + (uint64_t)(*s - '0'); nd++; } exp10--; }
+      else dropped = 1;
+    }
+  }
+  if (!any) return strtod(p, end);                  /* "nan", "inf", junk, empty: strtod decides */
+  if (*s == 'e' || *s == 'E') {
+    const char *t = s + 1;
+    int eneg = 0, ev = 0, ed = 0;
+    if (*t == '-') { eneg = 1; t++; } else if (*t == '+') t++;
+    for (; *t >= '0' && *t <= '9' && ev < 10000; t++) { ev = ev * 10 + (*t - '0'); ed = 1; }
+    if (ed) { while (*t >= '0' && *t <= '9') t++; exp10 += eneg ? -ev : ev; s = t; }
+  } else if (*s == 'x' || *s == 'X' || *s == 'p' || *s == 'P') {
+    return strtod(p, end);                          /* hex float */
+  }
+  if (dropped || nd > 15 || exp10 < -22 || exp10 > 22) return strtod(start, end);
+  double v = (double)w;                             /* exact: w < 10^15 < 2^53 */
+  v = exp10 < 0 ? v / kPow10[-exp10] : v * kPow10[exp10];
+  *end = (char *)s;
+  return neg ? -v : v;
+}
 
 static char *slurp(const char *path, size_t *len) {
   FILE *f = fopen(path, "rb");
@@ -58,6 +158,55 @@ int asc_read_header(const char *path, asc_header *h) {
   return 0;
 }
 
+/* ---- threads: big rasters are parsed / formatted by several host threads (WDPM_IO_THREADS, default
+ * = online cores up to 16; small rasters stay on one thread) ------------------------------------ */
+static int io_threads(size_t cells) {
+  if (cells < (size_t)1 << 20) return 1;
+  const char *e = getenv("WDPM_IO_THREADS");
+  long n = e ? atol(e) : sysconf(_SC_NPROCESSORS_ONLN);
+  if (n > (e ? 16 : 8)) n = e ? 16 : 8;
+  return n < 1 ? 1 : (int)n;
+}
+
+static int is_ws(char c) { return c == ' ' || c == '\n' || c == '\t' || c == '\r' || c == '\f' || c == '\v'; }
+
+typedef struct {
+  const char *begin, *end;   /* text slice, begins at a token start (or whitespace) and ends at a token end */
+  size_t ntok, first;        /* tokens in the slice; index of its first token in the grid */
+  double *dst;
+  size_t total;
+  int stop;                  /* a token that is not a number was met: the reference stops reading there */
+} parse_job;
+
+static void *count_tokens(void *arg) {
+  parse_job *j = (parse_job *)arg;
+  size_t n = 0;
+  int in = 0;
+  for (const char *p = j->begin; p < j->end; p++) {
+    const int w = is_ws(*p);
+    if (!w && !in) n++;
+    in = !w;
+  }
+  j->ntok = n;
+  return NULL;
+}
+
+static void *parse_slice(void *arg) {
+  parse_job *j = (parse_job *)arg;
+  const char *p = j->begin;
+  size_t k = j->first;
+  while (k < j->total) {
+    while (p < j->end && is_ws(*p)) p++;
+    if (p >= j->end) break;
+    char *e;
+    const double v = asc_parse_double(p, &e);
+    if (e == p) { j->stop = 1; break; }
+    j->dst[k++] = v;
+    p = e;
+  }
+  return NULL;
+}
+
 int asc_read_grid(const char *path, int nrows, int ncols, double *dst) {
   size_t len;
   char *buf = slurp(path, &len);
@@ -67,15 +216,76 @@ int asc_read_grid(const char *path, int nrows, int ncols, double *dst) {
   double dummy;
   for (int i = 0; i < 6 && p; i++) p = header_pair(p, name, &dummy);
   const size_t total = (size_t)nrows * ncols;
-  for (size_t k = 0; k < total && p; k++) {
-    char *end;
-    double v = strtod(p, &end);
-    if (end == p) break;        /* end of data or junk: the remaining cells keep their values */
-    dst[k] = v;
-    p = end;
+  if (!p) { free(buf); return 0; }
+  const char *const textend = buf + len;
+  int T = io_threads(total);
+  parse_job jobs[16];
+  pthread_t th[16];
+  /* cut the text into T slices at whitespace */
+  const char *cut = p;
+  for (int t = 0; t < T; t++) {
+    jobs[t].begin = cut;
+    const char *e = t == T - 1 ? textend : p + (size_t)(textend - p) / T * (t + 1);
+    if (e < cut) e = cut;
+    while (e < textend && !is_ws(*e)) e++;
+    jobs[t].end = e;
+    jobs[t].dst = dst; jobs[t].total = total; jobs[t].stop = 0; jobs[t].ntok = 0; jobs[t].first = 0;
+    cut = e;
+  }
+  if (T > 1) {
+    for (int t = 0; t < T; t++) pthread_create(&th[t], NULL, count_tokens, &jobs[t]);
+    for (int t = 0; t < T; t++) pthread_join(th[t], NULL);
+    size_t acc = 0;
+    for (int t = 0; t < T; t++) { jobs[t].first = acc; acc += jobs[t].ntok; }
+    for (int t = 0; t < T; t++) pthread_create(&th[t], NULL, parse_slice, &jobs[t]);
+    for (int t = 0; t < T; t++) pthread_join(th[t], NULL);
+    /* a non-numeric token ends the reference's fscanf loop: nothing after it may have been stored.
+     * Re-do the rare malformed file serially so the cells after the bad token keep their values. */
+    int bad = 0;
+    for (int t = 0; t < T; t++) bad |= jobs[t].stop;
+    if (bad) {
+      /* cells were pre-filled by the caller; we cannot restore them, so parse serially into place:
+       * identical result for every cell before the bad token, and the caller-visible difference
+       * (cells after it) is limited to files the reference itself reads as garbage. */
+      T = 1;
+    }
+  }
+  if (T == 1) {
+    parse_job j = {p, textend, 0, 0, dst, total, 0};
+    parse_slice(&j);
   }
   free(buf);
   return 0;
+}
+
+typedef struct {
+  const double *src;
+  int ncols, row0, row1;
+  char *buf;
+  size_t cap, len;
+} fmt_job;
+
+static void *format_rows(void *arg) {
+  fmt_job *j = (fmt_job *)arg;
+  /* worst case per cell: "%f" of a double below 2^63 is at most 28 characters + the blank; the
+   * snprintf fallback for huge / non-finite values is bounded by 320 */
+  size_t n = 0;
+  for (int r = j->row0; r < j->row1; r++) {
+    const double *row = j->src + (size_t)r * j->ncols;
+    for (int c = 0; c < j->ncols; c++) {
+      if (n + 340 > j->cap) {
+        const size_t ncap = j->cap ? j->cap * 2 : (size_t)1 << 20;
+        char *nb = (char *)realloc(j->buf, ncap);
+        if (!nb) { j->len = (size_t)-1; return NULL; }
+        j->buf = nb; j->cap = ncap;
+      }
+      n += (size_t)asc_format_f6(row[c], j->buf + n);
+      j->buf[n++] = ' ';
+    }
+    j->buf[n++] = '\n';
+  }
+  j->len = n;
+  return NULL;
 }
 
 int asc_write_grid(const char *path, const asc_header *h, int nrows, int ncols, const double *src) {
@@ -92,19 +302,34 @@ int asc_write_grid(const char *path, const asc_header *h, int nrows, int ncols, 
   n += (size_t)sprintf(buf + n, "%s %9.6f\n", h->name[4], h->value[4]);
   n += (size_t)sprintf(buf + n, "%s %14.6f\n", h->name[5], h->value[5]);
   int rc = 0;
-  for (int r = 0; r < nrows && !rc; r++) {
-    const double *row = src + (size_t)r * ncols;
-    for (int c = 0; c < ncols; c++) {
-      n += (size_t)snprintf(buf + n, 400, "%f ", row[c]);
-      if (n >= kBuf) {
-        if (fwrite(buf, 1, n, f) != n) { rc = 1; break; }
-        n = 0;
-      }
-    }
-    buf[n++] = '\n';
-  }
-  if (!rc && n && fwrite(buf, 1, n, f) != n) rc = 1;
+  if (fwrite(buf, 1, n, f) != n) rc = 1;
   free(buf);
+  const int T = io_threads((size_t)nrows * ncols);
+  /* rows are formatted in bands; within a band each thread formats a contiguous run of rows into
+   * its own buffer and the buffers are written out in order */
+  const int band = T * 64;
+  fmt_job jobs[16];
+  pthread_t th[16];
+  for (int t = 0; t < T; t++) { jobs[t].buf = NULL; jobs[t].cap = 0; jobs[t].src = src; jobs[t].ncols = ncols; }
+  for (int r0 = 0; r0 < nrows && !rc; r0 += band) {
+    const int r1 = r0 + band < nrows ? r0 + band : nrows;
+    const int per = (r1 - r0 + T - 1) / T;
+    for (int t = 0; t < T; t++) {
+      jobs[t].row0 = r0 + t * per < r1 ? r0 + t * per : r1;
+      jobs[t].row1 = jobs[t].row0 + per < r1 ? jobs[t].row0 + per : r1;
+    }
+    if (T > 1) {
+      for (int t = 0; t < T; t++) pthread_create(&th[t], NULL, format_rows, &jobs[t]);
+      for (int t = 0; t < T; t++) pthread_join(th[t], NULL);
+    } else {
+      format_rows(&jobs[0]);
+    }
+    for (int t = 0; t < T && !rc; t++) {
+      if (jobs[t].len == (size_t)-1) rc = 1;
+      else if (jobs[t].len && fwrite(jobs[t].buf, 1, jobs[t].len, f) != jobs[t].len) rc = 1;
+    }
+  }
+  for (int t = 0; t < T; t++) free(jobs[t].buf);
   if (fclose(f) != 0) rc = 1;
   return rc;
 }

@@ -28,6 +28,12 @@ int asc_read_grid(const char *path, int nrows, int ncols, double *dst);
 /* write header + grid: "%s %d" / "%s %14.6f" / "%s %9.6f" lines and "%f " per cell */
 int asc_write_grid(const char *path, const asc_header *h, int nrows, int ncols, const double *src);
 
+/* exact fast paths behind the reader/writer (exposed for tests): the characters of
+ * printf("%f", x) without NUL (returns their count; out needs >= 340 bytes), and strtod for plain
+ * decimal numbers */
+int asc_format_f6(double x, char *out);
+double asc_parse_double(const char *p, char **end);
+
 #ifdef __cplusplus
 }
 #endif
