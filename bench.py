@@ -106,20 +106,28 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # rehearsal on a box with fewer GPUs than ranks: WDPM_DIST_BACKEND=gloo WDPM_HALO=host lets several
+    # ranks share one GPU (RCCL refuses that); the driver's real runs use nccl, one GPU per rank
+    backend = os.environ.get("WDPM_DIST_BACKEND", "nccl")
+    ngpu = torch.cuda.device_count()
+    local_rank = local_rank % max(ngpu, 1)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     lib = wdpm_amd.load_hip()
     n = args.size
     kernel = {"auto": wdpm_amd.KERNEL_AUTO, "pass": wdpm_amd.KERNEL_PASS, "fused": wdpm_amd.KERNEL_FUSED}[args.kernel]
     transport = DeviceTransport(dist, torch.device("cuda", local_rank)) if world > 1 else None
-    if world > 1 and os.environ.get("WDPM_HALO", "device") == "host":
+    if world > 1 and (os.environ.get("WDPM_HALO", "device") == "host" or backend != "nccl"):
         # escape hatch: stage halo rows through host memory over a gloo group
         from wdpm_amd.rowblock import HostTransport
-        transport = HostTransport(dist, dist.new_group(backend="gloo"))
+        transport = HostTransport(dist, dist.new_group(backend="gloo") if backend == "nccl" else None)
     drain_kw = {}
     if args.module == "drain":
         # the outlet is the first row-major minimum of the DEM (WDPMCL.c:1005-1017), padded coordinates
@@ -149,7 +157,7 @@ def main():
         dr = drain_kw["drainrow"]
         w_out = float(bw[dr - s.row0, drain_kw["draincol"]]) if s.row0 <= dr < s.row0 + s.rows else 0.0
         if world > 1:
-            t = torch.tensor([w_out], dtype=torch.float64, device="cuda")
+            t = torch.tensor([w_out], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             w_out = float(t.item())
         solver.set_totaldrain(max(w_out, 0.0))
@@ -169,7 +177,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     launches, kernel_ms = solver.ctx.timing()

@@ -12,8 +12,8 @@ import numpy as np
 INF = np.inf
 LANES = 64
 STRIP_IN = 3 * LANES          # 192 columns loaded per wave
-HALO_L, HALO_R = 8, 16        # columns lost left / right per fused iteration
-STRIP_OUT = STRIP_IN - HALO_L - HALO_R  # 168
+HALO_L, HALO_R = 8, 13        # columns given up left / right per fused iteration (worst-case reach 8 / 12)
+STRIP_OUT = STRIP_IN - HALO_L - HALO_R  # 171, a multiple of 3 so every strip starts on a block boundary
 
 NB = [(-1, -1), (-1, 0), (-1, 1), (0, -1), (0, 1), (1, -1), (1, 0), (1, 1)]
 

@@ -18,8 +18,8 @@
  *  - Within a row alignment the three column alignments oj=1,2,3 shift the blocks right by one
  *    column each: the lane borrows column 0 (then column 1) of lane m+1 with a DPP wave_shl:1
  *    register move, updates it, and hands both back with wave_shr:1.  No LDS traffic.
- *  - Information moves at most 8 columns left / 16 right and 2 rows up / 4 down per iteration, so
- *    a wave's 192 x (H+6) input trapezoid yields a 168 x H exact output; neighbouring waves
+ *  - Information moves at most 8 columns left / 12 right and 2 rows up / 4 down per iteration, so
+ *    a wave's 192 x (H+6) input trapezoid yields a 171 x H exact output; neighbouring waves
  *    recompute the overlap (redundant, bit-identical work) instead of communicating.
  *  - Cells with bigdem <= missingvalue and cells outside the slab are held as dem = +inf: as a
  *    neighbour this makes ht_diff -inf/NaN, so `ht_diff > 0` is false with no extra test
@@ -37,14 +37,17 @@ namespace {
 
 constexpr int kLanes = 64;
 constexpr int kStripIn = 3 * kLanes;                     // 192 columns loaded per wave
-constexpr int kHaloL = 8, kHaloR = 16;                   // columns lost per fused iteration
-constexpr int kStripOut = kStripIn - kHaloL - kHaloR;    // 168 columns stored per wave
+// Per fused iteration an error at a strip's edge travels at most 8 columns inward from the left and
+// 12 from the right (cell-level dependency simulation, tests/test_rowblock.py); 13 are given up on
+// the right so that the strip pitch, 171, is a multiple of 3 and every strip starts on a block edge.
+constexpr int kHaloL = 8, kHaloR = 13;
+constexpr int kStripOut = kStripIn - kHaloL - kHaloR;    // 171 columns stored per wave
 
 #define WDPM_INF (__builtin_inf())
 
 /* value held by lane+1; lane 63 receives 0.0 (DPP bound_ctrl zero fill, so no register has to
  * be preset).  v_mov_b32_dpp wave_shl:1.  Lane 63's borrowed columns lie beyond the strip: its
- * blocks of passes oj=2,3 are inside the 16-column right halo whose results are never stored, so
+ * blocks of passes oj=2,3 are inside the right halo whose results are never stored, so
  * any finite fill is as good as the true value there. */
 __device__ __forceinline__ double lane_next(const double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);

@@ -42,8 +42,10 @@ pass_kernel(double *__restrict__ w, const double *__restrict__ dem, SlabGeom g, 
   const int bc = blockIdx.x * 64 + (threadIdx.x & 63);
   const int br = blockIdx.y * 4 + (threadIdx.x >> 6);
   const int c = oj + 3 * bc;   // centre column (padded coords)
-  const int r = oi + 3 * br;   // centre row, slab-local (row0 % 3 == 0 keeps the colour alignment)
-  if (c > g.C || r > g.rows - 2 || r + g.row0 > g.R) return;
+  // centre row, slab-local (row0 % 3 == 0 keeps the colour alignment); a slab that does not start at
+  // the raster's first row also has centres in its local row 0 (global row row0 = oi + 3j for oi = 3)
+  const int r = oi + 3 * br - (g.row0 > 0 && oi == 3 ? 3 : 0);
+  if (c > g.C || r > g.rows - 1 || r + g.row0 > g.R) return;
   const size_t ic = (size_t)r * g.ncp + c;
   const double dc_ = dem[ic];
   double wc = w[ic];
@@ -54,6 +56,7 @@ pass_kernel(double *__restrict__ w, const double *__restrict__ dem, SlabGeom g, 
 #pragma unroll
   for (int k = 0; k < 8; k++) {
     const int rr = r + nb_dr(k), cc = c + nb_dc(k);
+    if (rr < 0 || rr >= g.rows) continue;   // slab edge: rows outside the slab act as NODATA
     const size_t in = (size_t)rr * g.ncp + cc;
     const double dn = dem[in];
     if (!cell_valid(dn)) continue;
@@ -80,10 +83,11 @@ pass_kernel(double *__restrict__ w, const double *__restrict__ dem, SlabGeom g, 
 hipError_t wdpm_launch_pass(int module, double *w, const double *dem, const SlabGeom &g, int oi, int oj,
                             double *totaldrain, hipStream_t s) {
   const int nbc = (g.C - oj) / 3 + 1;               // centres oj, oj+3, ... <= C
-  int rmax = g.rows - 2;
+  int rmax = g.rows - 1;
   if (g.R - g.row0 < rmax) rmax = g.R - g.row0;
-  if (rmax < oi || g.C < oj) return hipSuccess;
-  const int nbr = (rmax - oi) / 3 + 1;
+  const int rfirst = oi - (g.row0 > 0 && oi == 3 ? 3 : 0);
+  if (rmax < rfirst || g.C < oj) return hipSuccess;
+  const int nbr = (rmax - rfirst) / 3 + 1;
   dim3 grid((nbc + 63) / 64, (nbr + 3) / 4);
   if (module == 2)
     hipLaunchKernelGGL(pass_kernel<2>, grid, dim3(256), 0, s, w, dem, g, oi, oj, totaldrain);

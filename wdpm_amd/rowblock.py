@@ -4,14 +4,21 @@ Host-side driver above the C ABI (include/wdpm.h), mirroring the reference's blo
 (src/WDPMCL.c:1049-1377) for a raster split into contiguous row slabs.  New work relative to the
 reference, which is single-device.
 
-Exactness.  One iteration moves information at most 2 rows up and 4 rows down (the 9-colour pass
-order shifts the 3x3 blocks down by one row twice per iteration); k iterations move it at most
-3k-1 rows up and 6k-2 rows down when the slab boundary L satisfies L % 3 == 2.  So a rank that
-owns rows [L, H] and holds halo rows [L-(3k-1), H+(6k-2)] can run k iterations with no
-communication and its owned rows stay bit-identical to the single-device result; the halos are
-then refreshed from the neighbours' owned rows (one send/recv pair per neighbour every k
-iterations, over RCCL/xGMI when the tensors live on GPUs).  The slab's first row L-(3k-1) is a
-multiple of 3, which keeps the colour alignment of every slab equal to the whole raster's.
+Exactness.  Rows outside a slab act as NODATA, so the rows next to a slab edge go wrong and the
+error creeps inward at the rate at which a cell can depend on other cells.  Inside a 3x3 block the
+centre depends on all nine cells and every neighbour on the centre and on the neighbours visited
+before it; chaining this over the three column alignments of a row alignment makes every row of
+a block depend on all three.  The block grid moves down one row per row alignment, so per
+iteration an error at the lower slab edge climbs 4 rows in the first iteration and 6 in each
+further one, and an error at the upper edge descends 2 rows, then 3 per iteration: k iterations
+need 3k-1 halo rows above and 6k-2 below when the slab boundary L satisfies L % 3 == 2
+(halo_depth(); tests/test_rowblock.py re-derives both numbers with a cell-level dependency
+("taint") simulation of the pass order, and shows on rasters that the rule is sufficient).  A rank
+that owns rows [L, H] and holds that halo runs k iterations with no communication and its owned
+rows stay bit-identical to the single-device result; the halos are then refreshed from the
+neighbours' owned rows (one send/recv pair per neighbour every k iterations, over RCCL/xGMI when
+the tensors live on GPUs).  The slab's first row L-(3k-1) is a multiple of 3, which keeps the
+colour alignment of every slab equal to the whole raster's.
 tests/test_rowblock.py checks all of this bit-for-bit on CPU ranks (gloo, world size 2 and 3).
 """
 from __future__ import annotations
@@ -44,7 +51,8 @@ class Slab:
 
 
 def halo_depth(k: int):
-    """(rows above, rows below) needed for k communication-free iterations."""
+    """(rows above, rows below) needed for k communication-free iterations (worst case over the
+    data; tests/test_rowblock.py re-derives both by a dependency simulation of the pass order)."""
     return 3 * k - 1, 6 * k - 2
 
 
