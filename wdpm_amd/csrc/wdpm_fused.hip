@@ -287,6 +287,23 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
                :                                                                                       \
                : "memory")
 
+    // the three staged rows [rb, rb+2] from LDS to HBM: 9 unconditional stores
+    auto store_rows = [&](const int rb) {
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        const int r = rb + i;
+        const bool row_ok = r >= or_lo && r <= or_hi;             // wave-uniform
+        // rows outside the chunk's output range (first / last trips only) go to the dump area
+        double *const orow = wout + (size_t)(row_ok ? r : 0) * pitch + c0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          const double v = stage_lds[i * kStripIn + scol[k]];
+          __builtin_nontemporal_store(v, row_ok ? orow + scol[k] : dump);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    };
+
     auto step = [&](const int n, double (&NW)[3][3], double (&ND)[3][3]) {
       // consume the prefetched rows into window slots 4..6; the device DEM already holds +inf for
       // NODATA cells, so only edge waves have anything to mask (outside the slab: dem=+inf, w=0)
@@ -311,6 +328,9 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
       }
       // always issued (the last trips re-read clamped / following rows and drop them)
       prefetch(NW, ND, A + 3 * (n + 1));
+      // the rows the previous step staged in LDS go out now, behind the new loads and ahead of a
+      // whole step of arithmetic (+1 % over storing at the end of the step); n = 0 has none: dump
+      store_rows(A + 3 * (n - 1) - 4);
 
       const int rbase = A + 3 * n - 4;                 // slab row of window slot 0
       stage<MODULE, SZ_SAFE, 4>(W, D, rbase + 4, g.dr, cdr, ds);   // oi = 1 on rows 3n   .. 3n+2
@@ -319,28 +339,16 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
 
       // rows 3n-4 .. 3n-2 have now seen all nine passes.  The wave transposes each row through its
       // private LDS slice (no barrier: a wave's LDS operations complete in order) so that every
-      // store instruction writes 512 contiguous bytes, streamed past the L2 (non-temporal).
+      // store instruction writes 512 contiguous bytes, streamed past the L2 (non-temporal); the
+      // stores themselves are issued by store_rows() at the top of the next step.
 #pragma unroll
       for (int i = 0; i < 3; i++)
 #pragma unroll
         for (int j = 0; j < 3; j++) stage_lds[i * kStripIn + 3 * lane + j] = W[i][j];
       __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int i = 0; i < 3; i++) {
-        const int r = rbase + i;
-        const bool row_ok = r >= or_lo && r <= or_hi;             // wave-uniform
-        // rows outside the chunk's output range (first / last trips only) go to the dump area
-        double *const orow = wout + (size_t)(row_ok ? r : 0) * pitch + c0;
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-          const double v = stage_lds[i * kStripIn + scol[k]];
-          __builtin_nontemporal_store(v, row_ok ? orow + scol[k] : dump);
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
       // The rows requested at the top of this step must have landed before the compiler may touch
       // their registers (it copies them around the loop back-edge): wait here, where the only
-      // younger memory operations are this step's 9 stores.
+      // younger memory operations are the 9 stores issued right after them.
       WDPM_WAIT_ROWS(9);
       // slide the window down three rows
 #pragma unroll
@@ -353,6 +361,7 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
     prefetch(NW, ND, A);
     WDPM_WAIT_ROWS(0);
     for (int n = 0; n < nsteps; n++) step(n, NW, ND);
+    store_rows(A + 3 * (nsteps - 1) - 4);      // the last step's rows
 #undef WDPM_WAIT_ROWS
   };
   if (edge) march(std::true_type{});
