@@ -123,11 +123,17 @@ def main():
     lib = wdpm_amd.load_hip()
     n = args.size
     kernel = {"auto": wdpm_amd.KERNEL_AUTO, "pass": wdpm_amd.KERNEL_PASS, "fused": wdpm_amd.KERNEL_FUSED}[args.kernel]
-    transport = DeviceTransport(dist, torch.device("cuda", local_rank)) if world > 1 else None
-    if world > 1 and (os.environ.get("WDPM_HALO", "device") == "host" or backend != "nccl"):
-        # escape hatch: stage halo rows through host memory over a gloo group
+    transport = fallback = None
+    if world > 1:
         from wdpm_amd.rowblock import HostTransport
-        transport = HostTransport(dist, dist.new_group(backend="gloo") if backend == "nccl" else None)
+        if backend == "nccl":
+            # GPU-direct halos over RCCL; a host-staged gloo path stands by should the platform refuse them
+            host = HostTransport(dist, dist.new_group(backend="gloo"))
+            transport, fallback = DeviceTransport(dist, torch.device("cuda", local_rank)), host
+            if os.environ.get("WDPM_HALO", "device") == "host":
+                transport, fallback = host, None
+        else:
+            transport = HostTransport(dist, None)
     drain_kw = {}
     if args.module == "drain":
         # the outlet is the first row-major minimum of the DEM (WDPMCL.c:1005-1017), padded coordinates
@@ -136,7 +142,8 @@ def main():
         drain_kw = dict(drainrow=k // n + 1, draincol=k % n + 1)
         del full
     solver = RowBlockSolver(lib, "add", n, n, MISSING, rank=rank, nranks=world, exchange_every=args.exchange_every,
-                            transport=transport, dist=dist, device=local_rank, kernel=kernel)
+                            transport=transport, dist=dist, device=local_rank, kernel=kernel,
+                            fallback_transport=fallback)
     solver.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     bd, bw = build_slab_inputs(lib, n, solver.slab)
     solver.ctx.upload(bd, bw)
@@ -148,7 +155,7 @@ def main():
         bw = solver.ctx.download_water()
         solver.close()
         solver = RowBlockSolver(lib, "drain", n, n, MISSING, rank=rank, nranks=world,
-                                exchange_every=args.exchange_every, transport=transport, dist=dist,
+                                exchange_every=args.exchange_every, transport=solver.transport, dist=dist,
                                 device=local_rank, kernel=kernel, **drain_kw)
         solver.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         solver.ctx.upload(bd, bw)

@@ -148,11 +148,11 @@ class RowBlockSolver:
 
     def __init__(self, lib: Lib, module, nrows: int, ncols: int, missingvalue: float, rank: int = 0,
                  nranks: int = 1, exchange_every: int = 4, transport=None, dist=None, drainrow: int = 0,
-                 draincol: int = 0, **ctx_kw):
+                 draincol: int = 0, fallback_transport=None, **ctx_kw):
         self.rank, self.nranks, self.k = rank, nranks, max(1, exchange_every)
         self.slabs = partition(nrows, nranks, self.k)
         self.slab = self.slabs[rank]
-        self.transport, self.dist = transport, dist
+        self.transport, self.dist, self.fallback_transport = transport, dist, fallback_transport
         if nranks > 1 and (transport is None or dist is None):
             raise ValueError("multi-rank solver needs a transport and torch.distributed")
         s = self.slab
@@ -207,7 +207,16 @@ class RowBlockSolver:
     def exchange(self):
         if self.nranks > 1:
             sends, recvs = self._plan()
-            self.transport.exchange(self.ctx, sends, recvs)
+            try:
+                self.transport.exchange(self.ctx, sends, recvs)
+            except Exception as e:  # noqa: BLE001 - e.g. a GPU-direct transport the platform refuses
+                if self.fallback_transport is None:
+                    raise
+                import sys
+                print(f"[wdpm rank {self.rank}] halo transport {type(self.transport).__name__} failed ({e!r}); "
+                      f"switching to {type(self.fallback_transport).__name__}", file=sys.stderr, flush=True)
+                self.transport, self.fallback_transport = self.fallback_transport, None
+                self.transport.exchange(self.ctx, sends, recvs)
         self._since_exchange = 0
 
     # -- the block loop pieces (WDPMCL.c:1055-1125, 1239-1254)
