@@ -127,6 +127,30 @@ int wdpm_synchronize(wdpm_ctx *ctx);
 int wdpm_timing_reset(wdpm_ctx *ctx);
 int wdpm_timing_get(wdpm_ctx *ctx, int64_t *launches, double *ms);
 
+/* copy `nrows` rows of the CURRENT water raster from slab-local row `src_row` of `src` to row
+ * `dst_row` of `dst` (same raster width).  Device to device on the HIP back-end (peer copy over
+ * xGMI when the contexts live on different GPUs), ordered after everything queued on either
+ * context.  This is the halo refresh primitive of single-process multi-GPU runs (wdpm_group_*). */
+int wdpm_copy_rows(wdpm_ctx *dst, int32_t dst_row, wdpm_ctx *src, int32_t src_row, int32_t nrows);
+
+/* -- a raster spread over several GPUs of one process (what WDPMCL uses when WDPM_GPUS > 1) ------
+ * Row-block decomposition: device g owns padded rows [L_g, H_g] (L_g % 3 == 2) and holds 3k-1
+ * halo rows above / 6k-2 below, runs k = exchange_every iterations without communication, then
+ * refreshes the halos from its neighbours' owned rows with wdpm_copy_rows.  Results are
+ * bit-identical to a single context.  `p` describes the WHOLE raster (slab/device fields ignored);
+ * devices[] may name the same device several times (testing on one GPU). */
+typedef struct wdpm_group wdpm_group;
+int  wdpm_group_create(wdpm_group **out, const wdpm_params *p, int32_t ndev, const int32_t *devices,
+                       int32_t exchange_every);
+void wdpm_group_destroy(wdpm_group *grp);
+int  wdpm_group_size(wdpm_group *grp);                      /* devices actually used */
+int  wdpm_group_upload(wdpm_group *grp, const double *bigdem, const double *bigwater);
+int  wdpm_group_download_water(wdpm_group *grp, double *bigwater);
+int  wdpm_group_set_totaldrain(wdpm_group *grp, double v);
+int  wdpm_group_get_totaldrain(wdpm_group *grp, double *v);
+int  wdpm_group_run_block(wdpm_group *grp, int32_t n_iter, double thres, double *max_diff);
+int  wdpm_group_drain_stats(wdpm_group *grp, double *diffdrain, double *final_sum);
+
 /* -- options -----------------------------------------------------------------------------------
  * WDPM_OPT_SIGNED_ZERO_SAFE (get/set): 1 = the add/subtract stencil must preserve the sign of
  *   zero-depth cells.  The library sets it by itself when an uploaded water raster contains -0.0

@@ -113,3 +113,26 @@ def test_hip_cli_baseline_configs(workdir, golden):
     err = check(HIP_CLI, golden, "cfg1_add100_k3000", workdir, "a100.asc")
     assert "hip-gfx950" in err
     param_file(HIP_CLI, golden, workdir)
+
+
+def multi_device(exe, golden, cwd, devices):
+    """WDPM_DEVICES spreads the raster over several contexts of one process (row blocks, halo copies):
+    reports and rasters must not change"""
+    env = dict(os.environ, WDPM_DEVICES=devices, WDPM_EXCHANGE_EVERY="3")
+    for key, outfile in (("val_add10", "a10.asc"), ("val_drain", "a10d.asc"), ("val_sub10", "a10s.asc")):
+        g = golden[key]
+        p = subprocess.run([exe] + g["args"], cwd=cwd, capture_output=True, text=True, timeout=1500, env=env)
+        assert p.returncode == 0, p.stderr
+        assert f"{len(devices.split(','))} devices" in p.stderr
+        blocks, summary = parse_report(p.stdout)
+        assert blocks == g["blocks"] and summary == g["summary"]
+        assert file_sha(os.path.join(cwd, outfile)) == g["out_sha256"]
+
+
+def test_cli_three_contexts_on_oracle_backend(workdir, golden):
+    multi_device(ORACLE_CLI, golden, workdir, "0,0,0")
+
+
+@pytest.mark.gpu
+def test_hip_cli_four_contexts_on_one_gpu(workdir, golden):
+    multi_device(HIP_CLI, golden, workdir, "0,0,0,0")

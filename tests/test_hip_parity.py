@@ -248,3 +248,49 @@ def test_synthetic_1024_drain_matches_oracle(hip, oracle):
         assert n_bit_diff(g.download_water(), o.download_water()) == 0
         assert g.totaldrain == o.totaldrain and g.totaldrain > 0
         assert g.drain_stats() == o.drain_stats()
+
+
+def test_subnormal_depths_are_not_flushed(hip, oracle):
+    """thres = 0 lets depths decay into the fp64 subnormal range (the reference's slow case on x86);
+    the GPU must keep them, bit for bit — no flush-to-zero anywhere in the kernels"""
+    dem, water, miss = random_case(41, 50, 210, dry_frac=0.2)
+    water = water * 1e-308                                  # 0 .. 3e-309: subnormal and near-subnormal
+    water[::7, ::5] = 5e-324
+    bd, bw = pad(dem, water, miss)
+    kw = dict(module="add", nrows=50, ncols=210, missingvalue=miss)
+    with hip.context(**kw) as g, oracle.context(**kw) as o:
+        g.upload(bd, bw)
+        o.upload(bd, bw)
+        assert g.run_block(30, 0.0) == o.run_block(30, 0.0)
+        wg, wo = g.download_water(), o.download_water()
+        assert n_bit_diff(wg, wo) == 0
+        assert ((wg > 0) & (wg < 2.2e-308)).any()           # subnormals survived
+
+
+def test_negative_elevations_and_other_nodata(hip, oracle):
+    """terrain below datum and a different NODATA code"""
+    rng = np.random.default_rng(42)
+    R, C, miss = 44, 260, -9999.0
+    dem = np.round(-120.0 + 3 * rng.standard_normal((R, C)).cumsum(axis=1) * 0.1, 3)
+    dem[rng.random((R, C)) < 0.07] = miss
+    water = np.where(dem > miss, rng.random((R, C)) * 0.2, 0.0)
+    bd, bw = pad(dem, water, miss)
+    for module in ("add", "drain"):
+        kw = dict(module=module, nrows=R, ncols=C, missingvalue=miss)
+        if module == "drain":
+            # no positive elevation: the reference's outlet search (bigdem > 0) finds nothing and keeps 0,0
+            kw.update(drainrow=0, draincol=0)
+        with hip.context(**kw) as g, oracle.context(**kw) as o:
+            g.upload(bd, bw)
+            o.upload(bd, bw)
+            g.iterate(12)
+            o.iterate(12)
+            assert n_bit_diff(g.download_water(), o.download_water()) == 0
+            assert g.totaldrain == o.totaldrain
+
+
+@pytest.mark.parametrize("R,C", [(1, 1), (1, 700), (2, 3), (600, 1), (3, 171), (4, 172), (23, 178), (24, 179)])
+def test_degenerate_shapes(hip, oracle, R, C):
+    """rasters thinner than a block, exactly one strip wide, one column past a strip, ..."""
+    _compare_with_oracle(hip, oracle, "add", R, C, seed=R * 7 + C, iters=(1, 5), kernel=wdpm_amd.KERNEL_FUSED)
+    _compare_with_oracle(hip, oracle, "drain", R, C, seed=R * 7 + C + 1, iters=(4,), kernel=wdpm_amd.KERNEL_FUSED)

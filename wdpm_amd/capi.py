@@ -64,6 +64,16 @@ SYMBOLS = {
     "wdpm_synchronize": (C.c_int, [_vp]),
     "wdpm_timing_reset": (C.c_int, [_vp]),
     "wdpm_timing_get": (C.c_int, [_vp, C.POINTER(C.c_int64), _dp]),
+    "wdpm_copy_rows": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, C.c_int32]),
+    "wdpm_group_create": (C.c_int, [C.POINTER(_vp), C.POINTER(Params), C.c_int32, C.POINTER(C.c_int32), C.c_int32]),
+    "wdpm_group_destroy": (None, [_vp]),
+    "wdpm_group_size": (C.c_int, [_vp]),
+    "wdpm_group_upload": (C.c_int, [_vp, _vp, _vp]),
+    "wdpm_group_download_water": (C.c_int, [_vp, _vp]),
+    "wdpm_group_set_totaldrain": (C.c_int, [_vp, C.c_double]),
+    "wdpm_group_get_totaldrain": (C.c_int, [_vp, _dp]),
+    "wdpm_group_run_block": (C.c_int, [_vp, C.c_int32, C.c_double, _dp]),
+    "wdpm_group_drain_stats": (C.c_int, [_vp, _dp, _dp]),
     "wdpm_get_option": (C.c_int, [_vp, C.c_int32, C.POINTER(C.c_int64)]),
     "wdpm_set_option": (C.c_int, [_vp, C.c_int32, C.c_int64]),
     "wdpm_synth_dem": (C.c_int, [C.c_int32, C.c_uint64, _vp]),

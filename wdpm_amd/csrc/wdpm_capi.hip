@@ -218,6 +218,27 @@ int wdpm_upload_rows(wdpm_ctx *x, int32_t row, int32_t nrows, const double *src)
   return note_negzero(x, row, nrows);
 }
 
+int wdpm_copy_rows(wdpm_ctx *dst, int32_t dst_row, wdpm_ctx *src, int32_t src_row, int32_t nrows) {
+  if (!dst || !src || dst->g.ncp != src->g.ncp || nrows < 0 || dst_row < 0 || src_row < 0 ||
+      dst_row + nrows > dst->g.rows || src_row + nrows > src->g.rows)
+    return fail("wdpm_copy_rows: bad row range");
+  if (nrows == 0) return 0;
+  /* everything queued on the source must have produced the rows, everything queued on the
+   * destination must be done with the rows being overwritten; the copy itself is synchronous
+   * with respect to the host so that the caller may launch on either context afterwards */
+  HIP_TRY(hipSetDevice(src->p.device));
+  HIP_TRY(hipStreamSynchronize(src->stream));
+  HIP_TRY(hipSetDevice(dst->p.device));
+  HIP_TRY(hipStreamSynchronize(dst->stream));
+  const size_t bytes = (size_t)nrows * src->g.ncp * sizeof(double);
+  double *d = dst->d_w[dst->cur] + (size_t)dst_row * dst->g.ncp;
+  const double *s = src->d_w[src->cur] + (size_t)src_row * src->g.ncp;
+  if (src->p.device == dst->p.device) HIP_TRY(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToDevice, dst->stream));
+  else HIP_TRY(hipMemcpyPeerAsync(d, dst->p.device, s, src->p.device, bytes, dst->stream));
+  HIP_TRY(hipStreamSynchronize(dst->stream));
+  return 0;
+}
+
 int wdpm_get_option(wdpm_ctx *x, int32_t key, int64_t *value) {
   if (key != WDPM_OPT_SIGNED_ZERO_SAFE || !value) return fail("wdpm_get_option: unknown option %d", key);
   *value = x->signed_zero_safe ? 1 : 0;

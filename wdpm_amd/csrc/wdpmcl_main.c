@@ -15,7 +15,9 @@
  *   - runoff.cl is not needed in the working directory.
  *   - malformed invocations that make the reference read uninitialised memory (unknown module with
  *     12/13 arguments, short parameter file) print the usage text and exit 42 instead.
- *   - WDPM_DEVICE=<n> selects the HIP device (default 0).
+ *   - WDPM_DEVICE=<n> selects the HIP device (default 0).  WDPM_GPUS=<N> spreads the raster over
+ *     devices 0..N-1 by row blocks (WDPM_DEVICES=a,b,c names them explicitly), exchanging halo rows
+ *     every WDPM_EXCHANGE_EVERY iterations (default 4); results do not depend on N.
  */
 #include <ctype.h>
 #include <math.h>
@@ -431,6 +433,22 @@ static void unpad_water(raster_state *s, int mask_missing) {
     }
 }
 
+/* devices to spread the raster over: WDPM_DEVICES=a,b,c | WDPM_GPUS=N (0..N-1) | WDPM_DEVICE=n | 0 */
+static int device_list(int32_t *dev, int max) {
+  const char *lst = getenv("WDPM_DEVICES");
+  int n = 0;
+  if (lst && *lst) {
+    char *copy = strdup(lst), *save = NULL;
+    for (char *t = strtok_r(copy, ",", &save); t && n < max; t = strtok_r(NULL, ",", &save)) dev[n++] = atoi(t);
+    free(copy);
+  } else if (getenv("WDPM_GPUS") && atoi(getenv("WDPM_GPUS")) > 1) {
+    const int want = atoi(getenv("WDPM_GPUS"));
+    for (n = 0; n < want && n < max; n++) dev[n] = n;
+  }
+  if (n == 0) dev[n++] = getenv("WDPM_DEVICE") ? atoi(getenv("WDPM_DEVICE")) : 0;
+  return n;
+}
+
 #define ABI_TRY(call)                                                      \
   do {                                                                     \
     if ((call) != 0) {                                                     \
@@ -501,12 +519,15 @@ int main(int argc, char **argv) {
   p.drainrow = st.drainrow;
   p.draincol = st.draincol;
   p.missingvalue = st.missing;
-  p.device = getenv("WDPM_DEVICE") ? atoi(getenv("WDPM_DEVICE")) : 0;
-  wdpm_ctx *ctx = NULL;
-  ABI_TRY(wdpm_create(&ctx, &p));
-  fprintf(stderr, "WDPMCL: redistribution loop on back-end %s, device %d\n", wdpm_backend_name(), p.device);
-  ABI_TRY(wdpm_upload(ctx, st.bigdem, st.bigwater));
-  if (cfg.module == WDPM_DRAIN) ABI_TRY(wdpm_set_totaldrain(ctx, st.totaldrain0));
+  int32_t devices[64];
+  int ndev = device_list(devices, 64);
+  wdpm_group *ctx = NULL;
+  ABI_TRY(wdpm_group_create(&ctx, &p, ndev, devices, getenv("WDPM_EXCHANGE_EVERY") ? atoi(getenv("WDPM_EXCHANGE_EVERY")) : 4));
+  ndev = wdpm_group_size(ctx);
+  fprintf(stderr, "WDPMCL: redistribution loop on back-end %s, %d device%s (first: %d)\n", wdpm_backend_name(), ndev,
+          ndev == 1 ? "" : "s, row-block decomposition", devices[0]);
+  ABI_TRY(wdpm_group_upload(ctx, st.bigdem, st.bigwater));
+  if (cfg.module == WDPM_DRAIN) ABI_TRY(wdpm_group_set_totaldrain(ctx, st.totaldrain0));
 
   /* block loop, WDPMCL.c:1049-1377 */
   struct timeval t0;
@@ -515,11 +536,11 @@ int main(int argc, char **argv) {
   int k = 0, done = 0;
   while (!done) {
     double max_diff = 0, diffdrain = 0, final_vol = 0;
-    ABI_TRY(wdpm_run_block(ctx, ITER_PER_BLOCK, thres, &max_diff));
+    ABI_TRY(wdpm_group_run_block(ctx, ITER_PER_BLOCK, thres, &max_diff));
     k += ITER_PER_BLOCK;
     if (cfg.module == WDPM_DRAIN) {
       double final_sum = 0;
-      ABI_TRY(wdpm_drain_stats(ctx, &diffdrain, &final_sum));
+      ABI_TRY(wdpm_group_drain_stats(ctx, &diffdrain, &final_sum));
       diffdrain *= st.cellarea;                                                /* :1258 */
       final_vol = final_sum * st.cellarea;                                     /* :1267 */
       printf("%7s %d %7s %8.3f %5s %10.1f %5s %12.1f %5s %8.2f\n", "", k, "", max_diff, "", diffdrain, "",
@@ -531,16 +552,16 @@ int main(int argc, char **argv) {
     if (cfg.module == WDPM_DRAIN && diffdrain < draintol) done = 1;            /* :1287,1303 */
     if (cfg.iteration_limit > 0 && k >= cfg.iteration_limit) done = 1;
     if (!done && write_scratch) {                                              /* checkpoint, :1290-1372 */
-      ABI_TRY(wdpm_download_water(ctx, st.bigwater));
+      ABI_TRY(wdpm_group_download_water(ctx, st.bigwater));
       unpad_water(&st, cfg.module == WDPM_ADD);
       asc_write_grid(cfg.scratch, &hdr, st.R, st.C, st.water);
     }
   }
 
   double totaldrain = 0;
-  ABI_TRY(wdpm_download_water(ctx, st.bigwater));
-  if (cfg.module == WDPM_DRAIN) ABI_TRY(wdpm_get_totaldrain(ctx, &totaldrain));
-  wdpm_destroy(ctx);
+  ABI_TRY(wdpm_group_download_water(ctx, st.bigwater));
+  if (cfg.module == WDPM_DRAIN) ABI_TRY(wdpm_group_get_totaldrain(ctx, &totaldrain));
+  wdpm_group_destroy(ctx);
 
   /* final statistics, WDPMCL.c:1379-1467 */
   unpad_water(&st, 1);
