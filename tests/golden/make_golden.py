@@ -226,6 +226,16 @@ def make_basin5_cli():
         # scratch/resume + water-file path: add 20 mm on top of a10.asc with a scratch file, limit 2000
         record("add20_on_a10_scratch", ["add", "basin5.asc", "a10.asc", "a30.asc", "scr.asc", 20, 0.5, 1.0, 0, 0, 0.005, 2000], "a30.asc")
         res["add20_on_a10_scratch"]["scratch_sha256"] = file_sha(os.path.join(td, "scr.asc"))
+        # BASELINE config 2 run to convergence at 10 mm (paper/paper.md:89: 179 000 iterations); ~7 min here.
+        # Only the last block, a hash of all block lines and the raster hash are kept.
+        rc, text = run_cli(["add", "basin5.asc", "NULL", "a300c.asc", "NULL", 300, 1.0, 10.0, 0, 0, 0.005, 0], td)
+        blocks, summary = parse_report(text)
+        res["cfg2_add300_converged"] = dict(
+            args=["add", "basin5.asc", "NULL", "a300.asc", "NULL", "300", "1.0", "10.0", "0", "0", "0.005", "0"], rc=rc,
+            n_blocks=len(blocks), last_block=blocks[-1],
+            blocks_sha256=hashlib.sha256(json.dumps(blocks).encode()).hexdigest(), summary=summary,
+            out_sha256=file_sha(os.path.join(td, "a300c.asc")),
+            report_sha256_nontiming=hashlib.sha256(strip_timing(text).encode()).hexdigest())
         # keep the 2x3 pothole patch the validation awk scripts sum (lines 268-269, fields 59-61)
         for key, fn in (("val_add10", "a10.asc"), ("val_drain", "a10d.asc"), ("val_sub10", "a10s.asc")):
             w, _ = read_asc(os.path.join(td, fn))

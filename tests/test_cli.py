@@ -136,3 +136,24 @@ def test_cli_three_contexts_on_oracle_backend(workdir, golden):
 @pytest.mark.gpu
 def test_hip_cli_four_contexts_on_one_gpu(workdir, golden):
     multi_device(HIP_CLI, golden, workdir, "0,0,0,0")
+
+
+@pytest.mark.gpu
+def test_hip_cli_add300_to_convergence(workdir, golden):
+    """BASELINE config 2 all the way: basin5, add 300 mm, tolerance 10 mm, no iteration limit.  The
+    unmodified reference needs 179 000 iterations (as paper/paper.md:89 reports) and 412 s on one core
+    of the build container; the HIP path must print the same 179 progress lines and write the same
+    bytes."""
+    import time
+    g = golden["cfg2_add300_converged"]
+    t = time.time()
+    rc, out, err = run(HIP_CLI, g["args"], workdir)
+    dt = time.time() - t
+    assert rc == 0, err
+    blocks, summary = parse_report(out)
+    assert len(blocks) == g["n_blocks"] == 179 and blocks[-1] == g["last_block"]
+    assert hashlib.sha256(json.dumps(blocks).encode()).hexdigest() == g["blocks_sha256"]
+    assert summary == g["summary"]
+    assert hashlib.sha256(strip_timing(out).encode()).hexdigest() == g["report_sha256_nontiming"]
+    assert file_sha(os.path.join(workdir, "a300.asc")) == g["out_sha256"]
+    print(f"WDPMCL add 300 mm to convergence on the HIP path: {dt:.1f} s wall (reference serial: 412 s)")

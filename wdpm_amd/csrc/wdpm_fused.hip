@@ -417,7 +417,9 @@ static int pick_chunk_rows(const int rows, const int nstrips, const int override
     int nch = slots / nstrips;
     if (nch < 1) nch = 1;
     H = ((rows - 2 + nch - 1) / nch + 2) / 3 * 3;
-    if (H < 24) H = 24;
+    // small rasters cannot fill the chip: short chunks then cost redundant warm-up rows on CUs that
+    // would idle anyway and cut the launch's critical path (a wave's march) to a few steps
+    if (H < 6) H = 6;
   }
   if (H > rows) H = (rows + 2) / 3 * 3;
   if (H < 3) H = 3;
