@@ -318,7 +318,13 @@ int wdpm_iterate(wdpm_ctx *x, int32_t n_iter) {
   else { HIP_TRY(hipEventCreate(&ep.a)); HIP_TRY(hipEventCreate(&ep.b)); }
   HIP_TRY(hipEventRecord(ep.a, x->stream));
   for (int it = 0; it < n_iter; it++) {
-    if (x->kernel == WDPM_KERNEL_FUSED) {
+    if (x->kernel == WDPM_KERNEL_FUSED2 && x->p.module != WDPM_DRAIN && n_iter - it >= 2) {
+      HIP_TRY(wdpm_launch_fused2(x->d_w[x->cur], x->d_w[x->cur ^ 1], x->d_dem, x->g, x->p.chunk_rows,
+                                 x->signed_zero_safe ? 1 : 0, x->stream));
+      x->cur ^= 1;
+      x->launches += 1;
+      it++;                      /* this launch was two iterations */
+    } else if (x->kernel == WDPM_KERNEL_FUSED || x->kernel == WDPM_KERNEL_FUSED2) {
       HIP_TRY(wdpm_launch_fused(x->p.module, x->d_w[x->cur], x->d_w[x->cur ^ 1], x->d_dem, x->g, x->p.chunk_rows,
                                 x->signed_zero_safe ? 1 : 0, x->d_scal, x->stream));
       x->cur ^= 1;

@@ -376,6 +376,216 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// TWO iterations per launch (add / subtract): 12 B of HBM traffic per cell-update instead of 24.
+//
+// The one-iteration kernel above is bound by HBM (profiles/r01: ~4.8 TB/s of real traffic), so the
+// next step is to touch HBM once per two iterations.  Holding a second iteration's window in the
+// same wave would need ~13 rows x 3 columns x (dem + water) = 156 VGPRs on top of everything else;
+// instead two waves of a workgroup form a pipeline over the same strip and chunk:
+//   producer  loads dem + water from HBM, runs iteration 1 exactly like the kernel above, and writes
+//             every finished row - lane for lane, no transpose - into an LDS ring of 12 rows;
+//   consumer  runs three steps behind, takes its water rows from the ring (its dem rows from
+//             HBM/L2: the producer has just pulled them in), runs iteration 2 and stores the result.
+// One s_barrier per step keeps the pair in lockstep.  The dependency cone of two iterations is
+// 17 columns left / 30 right and 5 rows up / 10 down (tests/test_rowblock.py), so a pair loads a
+// 192 x (H+15) block and stores an exact 144 x H block; tests/fused_model.py::fused2_iterations is
+// the numpy model of this schedule, checked bit-for-bit against the oracle.
+// ---------------------------------------------------------------------------------------------
+constexpr int kHalo2L = 17, kHalo2R = 31;                    // 31: strip pitch 144 is a multiple of 3
+constexpr int kStripOut2 = kStripIn - kHalo2L - kHalo2R;     // 144
+constexpr int kRingRows = 12, kLag = 3;
+
+template <bool SZ_SAFE>
+__global__ void __launch_bounds__(256, WDPM_FUSED_MIN_WAVES)
+fused2_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout,
+                        const double *__restrict__ dem, const SlabGeom g, const int nstrips,
+                        const int nitems, const int H) {
+  const int lane = threadIdx.x & 63;
+  const int vb = (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8;      // XCD-contiguous strips
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int pair = wave >> 1;
+  const bool producer = (wave & 1) == 0;
+  const int item = vb * 2 + pair;
+  if (item >= nitems) return;               // both waves of the pair leave; ended waves do not count at s_barrier
+  const int strip = item % nstrips, chunk = item / nstrips;
+  const int c0 = kStripOut2 * strip;
+  const int oc_lo = strip == 0 ? 0 : c0 + kHalo2L;
+  const int oc_hi = c0 + kStripIn - 1 - kHalo2R;
+  const int A = H * chunk;
+  const int nsA = H / 3 + 5, nsB = H / 3 + 3;
+  const int or_lo = chunk == 0 ? 0 : A + 5;
+  int or_hi = H * (chunk + 1) + 4;
+  if (or_hi > g.rows - 1) or_hi = g.rows - 1;
+  const int colb = c0 + 3 * lane;
+  const size_t pitch = (size_t)g.ncp;
+
+  __shared__ double ring_all[2][kRingRows * kStripIn];     // 18 KiB per pair
+  __shared__ double stage_all[2][3 * kStripIn];            // consumer's store transpose, 4.5 KiB per pair
+  double *const ring = ring_all[pair];
+  double *const stage_lds = stage_all[pair];
+
+  int scol[3];
+  {
+    const int lo = oc_lo - c0;
+    const int hi = (oc_hi < g.ncp - 1 ? oc_hi : g.ncp - 1) - c0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) scol[k] = lo + 64 * k + lane < hi ? lo + 64 * k + lane : hi;
+  }
+  double *const dump = wout + (size_t)g.rows * pitch + lane;
+  bool cdr[5] = {false, false, false, false, false};
+  DrainState ds;
+  ds.td = 0.0;
+  ds.hit = false;
+
+  double W[7][3], D[7][3];
+#pragma unroll
+  for (int k = 0; k < 7; k++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) { W[k][j] = 0.0; D[k][j] = WDPM_INF; }
+
+  const bool edge = (c0 + kStripIn > g.ncp) || (A + 3 * (nsA + 1) > g.rows);
+  int voff[3];
+#pragma unroll
+  for (int j = 0; j < 3; j++) voff[j] = 8 * (edge ? (colb + j < g.ncp ? colb + j : g.ncp - 1) : colb + j);
+
+  // three rows starting at slab row r0 of one raster into raw registers (see the kernel above)
+  auto load3 = [&](const double *base, double (&N)[3][3], const int r0) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      int r = r0 + i;
+      r = r < g.rows ? r : g.rows - 1;
+      const double *b = base + (size_t)r * pitch;           // wave-uniform
+#pragma unroll
+      for (int j = 0; j < 3; j++)
+        asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(N[i][j]) : "v"(voff[j]), "s"(b) : "memory");
+    }
+  };
+#define WDPM_WAIT9(N, YOUNGER)                                                                          \
+  asm volatile("s_waitcnt vmcnt(" #YOUNGER ")"                                                          \
+               : "+v"(N[0][0]), "+v"(N[0][1]), "+v"(N[0][2]), "+v"(N[1][0]), "+v"(N[1][1]), "+v"(N[1][2]), \
+                 "+v"(N[2][0]), "+v"(N[2][1]), "+v"(N[2][2])                                            \
+               :                                                                                        \
+               : "memory")
+  // cells outside the slab: dem = +inf, water = 0 (only edge pairs can see any)
+  auto mask_outside = [&](const int r0) {
+    if (edge) {
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        const bool row_ok = r0 + i < g.rows;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          const bool ok = row_ok & (colb + j < g.ncp);
+          W[4 + i][j] = ok ? W[4 + i][j] : 0.0;
+          D[4 + i][j] = ok ? D[4 + i][j] : WDPM_INF;
+        }
+      }
+    }
+  };
+  auto slide = [&]() {
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) { W[k][j] = W[k + 3][j]; D[k][j] = D[k + 3][j]; }
+  };
+  // LDS writes of this wave are complete, then the pair (and its sibling pair) meet
+  auto pair_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+  double NW[3][3], ND[3][3];
+  if (producer) {
+    load3(win, NW, A);
+    load3(dem, ND, A);
+    WDPM_WAIT9(NW, 0);
+    WDPM_WAIT9(ND, 0);
+    for (int R = 0; R < nsA + kLag; R++) {
+      if (R < nsA) {
+        const int n = R;
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+          for (int j = 0; j < 3; j++) { W[4 + i][j] = NW[i][j]; D[4 + i][j] = ND[i][j]; }
+        mask_outside(A + 3 * n);
+        load3(win, NW, A + 3 * (n + 1));
+        load3(dem, ND, A + 3 * (n + 1));
+        const int rbase = A + 3 * n - 4;
+        stage<0, SZ_SAFE, 4>(W, D, rbase + 4, 0, cdr, ds);
+        stage<0, SZ_SAFE, 2>(W, D, rbase + 2, 0, cdr, ds);
+        stage<0, SZ_SAFE, 0>(W, D, rbase + 0, 0, cdr, ds);
+        // rows 3n-4 .. 3n-2 have finished iteration 1: hand them to the consumer, lane for lane
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          const int slot = (3 * n - 4 + i + 2 * kRingRows) % kRingRows;
+#pragma unroll
+          for (int j = 0; j < 3; j++) ring[slot * kStripIn + 3 * lane + j] = W[i][j];
+        }
+        WDPM_WAIT9(NW, 0);          // no younger memory operations: the producer does not store to HBM
+        WDPM_WAIT9(ND, 0);
+        slide();
+      }
+      pair_barrier();
+    }
+  } else {
+    load3(dem, ND, A);
+    WDPM_WAIT9(ND, 0);
+    for (int R = 0; R < nsA + kLag; R++) {
+      const int m = R - kLag;
+      if (m >= 0 && m < nsB) {
+        // iteration-1 rows 3m .. 3m+2 from the ring (written at least one barrier ago), dem prefetched
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          const int slot = (3 * m + i) % kRingRows;
+#pragma unroll
+          for (int j = 0; j < 3; j++) { W[4 + i][j] = ring[slot * kStripIn + 3 * lane + j]; D[4 + i][j] = ND[i][j]; }
+        }
+        mask_outside(A + 3 * m);
+        load3(dem, ND, A + 3 * (m + 1));
+        // the rows staged by the previous step go out now (9 unconditional stores; dump for m = 0)
+        {
+          const int rb = A + 3 * (m - 1) - 4;
+#pragma unroll
+          for (int i = 0; i < 3; i++) {
+            const int r = rb + i;
+            const bool row_ok = r >= or_lo && r <= or_hi;
+            double *const orow = wout + (size_t)(row_ok ? r : 0) * pitch + c0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+              const double v = stage_lds[i * kStripIn + scol[k]];
+              __builtin_nontemporal_store(v, row_ok ? orow + scol[k] : dump);
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+        const int rbase = A + 3 * m - 4;
+        stage<0, SZ_SAFE, 4>(W, D, rbase + 4, 0, cdr, ds);
+        stage<0, SZ_SAFE, 2>(W, D, rbase + 2, 0, cdr, ds);
+        stage<0, SZ_SAFE, 0>(W, D, rbase + 0, 0, cdr, ds);
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+          for (int j = 0; j < 3; j++) stage_lds[i * kStripIn + 3 * lane + j] = W[i][j];
+        __builtin_amdgcn_wave_barrier();
+        WDPM_WAIT9(ND, 9);          // younger than the dem loads: this step's 9 stores
+        slide();
+      }
+      pair_barrier();
+    }
+    // the last step's rows
+    const int rb = A + 3 * (nsB - 1) - 4;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const int r = rb + i;
+      const bool row_ok = r >= or_lo && r <= or_hi;
+      double *const orow = wout + (size_t)(row_ok ? r : 0) * pitch + c0;
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const double v = stage_lds[i * kStripIn + scol[k]];
+        __builtin_nontemporal_store(v, row_ok ? orow + scol[k] : dump);
+      }
+    }
+  }
+#undef WDPM_WAIT9
+}
+
 __global__ void dpp_probe_kernel(int *out) {
   const int lane = threadIdx.x;
   const double v = (double)lane;
@@ -446,6 +656,39 @@ static hipError_t dpp_selfcheck(hipStream_t s) {
   }
   state = ok ? 1 : -1;
   return ok ? hipSuccess : hipErrorUnknown;
+}
+
+template <bool SZ_SAFE>
+static int resident_pairs() {
+  static int cached = 0;
+  if (cached) return cached;
+  int dev = 0, cus = 256, blocks = 2;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, fused2_iteration_kernel<SZ_SAFE>, 256, 0) != hipSuccess || blocks < 1)
+    blocks = 2;
+  cached = cus * blocks * 2;
+  return cached;
+}
+
+/* two iterations (add / subtract) in one pass over the raster: w_in -> w_out */
+hipError_t wdpm_launch_fused2(const double *w_in, double *w_out, const double *dem, const SlabGeom &g,
+                              int chunk_rows, int signed_zero_safe, hipStream_t s) {
+  hipError_t e = dpp_selfcheck(s);
+  if (e != hipSuccess) return e;
+  int nstrips = 1;
+  if (g.ncp > kStripIn - kHalo2R) nstrips = (g.ncp - (kStripIn - kHalo2R) + kStripOut2 - 1) / kStripOut2 + 1;
+  const int slots = signed_zero_safe ? resident_pairs<true>() : resident_pairs<false>();
+  const int H = pick_chunk_rows(g.rows, nstrips, chunk_rows, slots);
+  // chunk i stores rows [H*i+5 (0 for i=0), H*(i+1)+4]; the last must reach row rows-1
+  int nchunks = (g.rows - 5 + H - 1) / H;
+  if (nchunks < 1) nchunks = 1;
+  const int nitems = nstrips * nchunks;
+  const dim3 grid(((nitems + 1) / 2 + 7) / 8 * 8), block(256);
+  if (signed_zero_safe)
+    hipLaunchKernelGGL((fused2_iteration_kernel<true>), grid, block, 0, s, w_in, w_out, dem, g, nstrips, nitems, H);
+  else
+    hipLaunchKernelGGL((fused2_iteration_kernel<false>), grid, block, 0, s, w_in, w_out, dem, g, nstrips, nitems, H);
+  return hipGetLastError();
 }
 
 hipError_t wdpm_launch_fused(int module, const double *w_in, double *w_out, const double *dem,
