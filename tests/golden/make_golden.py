@@ -226,6 +226,11 @@ def make_basin5_cli():
         # scratch/resume + water-file path: add 20 mm on top of a10.asc with a scratch file, limit 2000
         record("add20_on_a10_scratch", ["add", "basin5.asc", "a10.asc", "a30.asc", "scr.asc", 20, 0.5, 1.0, 0, 0, 0.005, 2000], "a30.asc")
         res["add20_on_a10_scratch"]["scratch_sha256"] = file_sha(os.path.join(td, "scr.asc"))
+        # resume: the scratch file left by the previous run exists, so it replaces the water file and the
+        # 20 mm are NOT added again (WDPMCL.c:668-673); three more blocks, two more scratch rewrites
+        record("resume_from_scratch", ["add", "basin5.asc", "a10.asc", "a30r.asc", "scr.asc", 20, 0.5, 0.5, 0, 0, 0.005, 3000],
+               "a30r.asc")
+        res["resume_from_scratch"]["scratch_sha256"] = file_sha(os.path.join(td, "scr.asc"))
         # BASELINE config 2 run to convergence at 10 mm (paper/paper.md:89: 179 000 iterations); ~7 min here.
         # Only the last block, a hash of all block lines and the raster hash are kept.
         rc, text = run_cli(["add", "basin5.asc", "NULL", "a300c.asc", "NULL", 300, 1.0, 10.0, 0, 0, 0.005, 0], td)

@@ -60,6 +60,10 @@ def chain(exe, golden, cwd):
     check(exe, golden, "val_sub10", cwd, "a10s.asc")
     check(exe, golden, "add20_on_a10_scratch", cwd, "a30.asc")
     assert file_sha(os.path.join(cwd, "scr.asc")) == golden["add20_on_a10_scratch"]["scratch_sha256"]
+    # resume from that scratch file: several scratch rewrites by the writer thread, the one left behind
+    # must be the state after the last non-final block, as with the reference
+    check(exe, golden, "resume_from_scratch", cwd, "a30r.asc")
+    assert file_sha(os.path.join(cwd, "scr.asc")) == golden["resume_from_scratch"]["scratch_sha256"]
 
 
 def usage(exe, golden, cwd):

@@ -21,6 +21,7 @@
  */
 #include <ctype.h>
 #include <math.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -449,6 +450,82 @@ static int device_list(int32_t *dev, int max) {
   return n;
 }
 
+/* ---- scratch (checkpoint) writer -------------------------------------------------------------
+ * The reference rewrites the scratch raster after every block that does not end the run
+ * (WDPMCL.c:1290-1372) and stalls the loop while fprintf runs.  Here the loop only pays for the
+ * device-to-host copy: the text is produced by a writer thread while the next blocks compute.  The
+ * writer always takes the NEWEST pending state (an older one that never reached the disk is simply
+ * superseded) and main() waits for it before exiting, so the file left behind is the one the
+ * reference leaves: the state after the last non-final block. */
+typedef struct {
+  pthread_t thread;
+  pthread_mutex_t mu;
+  pthread_cond_t cv;
+  const char *path;
+  const asc_header *hdr;
+  int R, C;
+  double *pending;   /* newest state not yet picked up by the writer, or NULL */
+  double *spare;     /* buffer the producer may fill next */
+  int busy, quit, started;
+} scratch_writer;
+
+static void *scratch_main(void *arg) {
+  scratch_writer *w = (scratch_writer *)arg;
+  pthread_mutex_lock(&w->mu);
+  for (;;) {
+    while (!w->pending && !w->quit) pthread_cond_wait(&w->cv, &w->mu);
+    if (!w->pending) break;                       /* quit and nothing left to write */
+    double *job = w->pending;
+    w->pending = NULL;
+    w->busy = 1;
+    pthread_mutex_unlock(&w->mu);
+    asc_write_grid(w->path, w->hdr, w->R, w->C, job);
+    pthread_mutex_lock(&w->mu);
+    w->busy = 0;
+    if (!w->spare) w->spare = job; else free(job);
+    pthread_cond_broadcast(&w->cv);
+  }
+  pthread_mutex_unlock(&w->mu);
+  return NULL;
+}
+
+static void scratch_start(scratch_writer *w, const char *path, const asc_header *hdr, int R, int C) {
+  memset(w, 0, sizeof *w);
+  pthread_mutex_init(&w->mu, NULL);
+  pthread_cond_init(&w->cv, NULL);
+  w->path = path; w->hdr = hdr; w->R = R; w->C = C;
+  w->started = pthread_create(&w->thread, NULL, scratch_main, w) == 0;
+}
+
+/* hand over a copy of the un-padded raster (takes the cells from `water`) */
+static void scratch_submit(scratch_writer *w, const double *water) {
+  const size_t bytes = (size_t)w->R * w->C * sizeof(double);
+  if (!w->started) { asc_write_grid(w->path, w->hdr, w->R, w->C, water); return; }
+  pthread_mutex_lock(&w->mu);
+  double *buf = w->pending ? w->pending : w->spare;    /* supersede an unwritten older state */
+  if (buf == w->spare) w->spare = NULL;
+  w->pending = NULL;
+  pthread_mutex_unlock(&w->mu);
+  if (!buf) buf = (double *)malloc(bytes);
+  if (!buf) { asc_write_grid(w->path, w->hdr, w->R, w->C, water); return; }
+  memcpy(buf, water, bytes);
+  pthread_mutex_lock(&w->mu);
+  w->pending = buf;
+  pthread_cond_broadcast(&w->cv);
+  pthread_mutex_unlock(&w->mu);
+}
+
+static void scratch_finish(scratch_writer *w) {
+  if (!w->started) return;
+  pthread_mutex_lock(&w->mu);
+  w->quit = 1;
+  pthread_cond_broadcast(&w->cv);
+  pthread_mutex_unlock(&w->mu);
+  pthread_join(w->thread, NULL);
+  free(w->spare);
+  free(w->pending);
+}
+
 #define ABI_TRY(call)                                                      \
   do {                                                                     \
     if ((call) != 0) {                                                     \
@@ -533,6 +610,8 @@ int main(int argc, char **argv) {
   struct timeval t0;
   gettimeofday(&t0, NULL);
   const int write_scratch = !is_null_name(cfg.scratch);
+  scratch_writer scratch;
+  if (write_scratch) scratch_start(&scratch, cfg.scratch, &hdr, st.R, st.C);
   int k = 0, done = 0;
   while (!done) {
     double max_diff = 0, diffdrain = 0, final_vol = 0;
@@ -554,9 +633,10 @@ int main(int argc, char **argv) {
     if (!done && write_scratch) {                                              /* checkpoint, :1290-1372 */
       ABI_TRY(wdpm_group_download_water(ctx, st.bigwater));
       unpad_water(&st, cfg.module == WDPM_ADD);
-      asc_write_grid(cfg.scratch, &hdr, st.R, st.C, st.water);
+      scratch_submit(&scratch, st.water);
     }
   }
+  if (write_scratch) scratch_finish(&scratch);
 
   double totaldrain = 0;
   ABI_TRY(wdpm_group_download_water(ctx, st.bigwater));
