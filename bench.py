@@ -86,7 +86,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--size", type=int, default=16384)
     ap.add_argument("--exchange-every", type=int, default=int(os.environ.get("WDPM_EXCHANGE_EVERY", "4")))
-    ap.add_argument("--kernel", choices=["auto", "pass", "fused", "fused2"], default="auto")
+    ap.add_argument("--kernel", choices=["auto", "pass", "fused", "fused2", "fused2w"], default="auto")
     ap.add_argument("--module", choices=["add", "drain"], default="add",
                     help="drain = BASELINE config 5: water-in is the add-100-mm state after --drain-spinup iterations")
     ap.add_argument("--drain-spinup", type=int, default=1000)
@@ -123,7 +123,7 @@ def main():
     lib = wdpm_amd.load_hip()
     n = args.size
     kernel = {"auto": wdpm_amd.KERNEL_AUTO, "pass": wdpm_amd.KERNEL_PASS, "fused": wdpm_amd.KERNEL_FUSED,
-              "fused2": wdpm_amd.KERNEL_FUSED2}[args.kernel]
+              "fused2": wdpm_amd.KERNEL_FUSED2, "fused2w": wdpm_amd.KERNEL_FUSED2W}[args.kernel]
     transport = fallback = None
     if world > 1:
         from wdpm_amd.rowblock import HostTransport

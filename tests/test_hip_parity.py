@@ -31,7 +31,8 @@ class KernelLib:
 @pytest.mark.parametrize("kernel,chunk", [(wdpm_amd.KERNEL_PASS, 0), (wdpm_amd.KERNEL_FUSED, 0),
                                           (wdpm_amd.KERNEL_FUSED, 3), (wdpm_amd.KERNEL_FUSED, 12),
                                           (wdpm_amd.KERNEL_FUSED2, 0), (wdpm_amd.KERNEL_FUSED2, 3),
-                                          (wdpm_amd.KERNEL_FUSED2, 12)])
+                                          (wdpm_amd.KERNEL_FUSED2, 12), (wdpm_amd.KERNEL_FUSED2W, 0),
+                                          (wdpm_amd.KERNEL_FUSED2W, 6)])
 def test_golden_stencil_vectors(hip, stencil_cases, kernel, chunk):
     z, index = stencil_cases
     assert check_stencil_cases(KernelLib(hip, kernel=kernel, chunk_rows=chunk), z, index) > 100
@@ -66,7 +67,8 @@ def _compare_with_oracle(hip, oracle, module, R, C, seed, iters, kernel, chunk=0
                 assert g.drain_stats() == o.drain_stats()
 
 
-@pytest.mark.parametrize("kernel", [wdpm_amd.KERNEL_PASS, wdpm_amd.KERNEL_FUSED, wdpm_amd.KERNEL_FUSED2])
+@pytest.mark.parametrize("kernel", [wdpm_amd.KERNEL_PASS, wdpm_amd.KERNEL_FUSED, wdpm_amd.KERNEL_FUSED2,
+                                    wdpm_amd.KERNEL_FUSED2W])
 @pytest.mark.parametrize("module", ["add", "drain"])
 @pytest.mark.parametrize("R,C,chunk", [(38, 398, 12), (100, 700, 0), (301, 170, 48), (64, 1100, 30), (5, 175, 3)])
 def test_random_rasters_match_oracle(hip, oracle, module, kernel, R, C, chunk):
@@ -300,11 +302,18 @@ def test_degenerate_shapes(hip, oracle, R, C):
 
 @pytest.mark.parametrize("R,C,chunk,iters", [(120, 333, 0, (2, 4, 40)), (61, 500, 9, (6,)), (300, 145, 24, (2, 2)),
                                              (35, 1000, 0, (8,)), (5, 144, 3, (2,)), (1, 1, 0, (2,))])
-def test_two_iteration_kernel_matches_oracle(hip, oracle, R, C, chunk, iters):
-    """FUSED2: producer/consumer wave pairs, two iterations per pass over the raster"""
-    _compare_with_oracle(hip, oracle, "add", R, C, seed=R + 3 * C, iters=iters, kernel=wdpm_amd.KERNEL_FUSED2, chunk=chunk)
-    _compare_with_oracle(hip, oracle, "subtract", R, C, seed=R + 3 * C + 1, iters=iters, kernel=wdpm_amd.KERNEL_FUSED2,
+@pytest.mark.parametrize("kernel", [wdpm_amd.KERNEL_FUSED2, wdpm_amd.KERNEL_FUSED2W])
+def test_two_iteration_kernel_matches_oracle(hip, oracle, R, C, chunk, iters, kernel):
+    """FUSED2 / FUSED2W: producer/consumer wave pairs, two iterations per pass over the raster"""
+    _compare_with_oracle(hip, oracle, "add", R, C, seed=R + 3 * C, iters=iters, kernel=kernel, chunk=chunk)
+    _compare_with_oracle(hip, oracle, "subtract", R, C, seed=R + 3 * C + 1, iters=iters, kernel=kernel,
                          chunk=chunk, thres=0.005 / 1000)
+
+
+@pytest.mark.parametrize("R,C", [(40, 336), (41, 337), (30, 353), (30, 354), (60, 800), (9, 2000)])
+def test_wide_kernel_strip_boundaries(hip, oracle, R, C):
+    """rasters one strip wide, one column past a strip, several 336-column strips"""
+    _compare_with_oracle(hip, oracle, "add", R, C, seed=5 * R + C, iters=(2, 6), kernel=wdpm_amd.KERNEL_FUSED2W)
 
 
 def test_two_iteration_kernel_full_size(hip):
@@ -314,12 +323,13 @@ def test_two_iteration_kernel_full_size(hip):
     bd, bw = pad(dem, np.full((n, n), 0.1), miss)
     kw = dict(module="add", nrows=n, ncols=n, missingvalue=miss)
     out = {}
-    for kernel in (wdpm_amd.KERNEL_FUSED, wdpm_amd.KERNEL_FUSED2):
+    for kernel in (wdpm_amd.KERNEL_FUSED, wdpm_amd.KERNEL_FUSED2, wdpm_amd.KERNEL_FUSED2W):
         with hip.context(kernel=kernel, **kw) as c:
             c.upload(bd, bw)
             c.iterate(20)
             a = c.download_water()
             c.iterate(7)
             out[kernel] = (a, c.download_water())
-    assert n_bit_diff(out[wdpm_amd.KERNEL_FUSED][0], out[wdpm_amd.KERNEL_FUSED2][0]) == 0
-    assert n_bit_diff(out[wdpm_amd.KERNEL_FUSED][1], out[wdpm_amd.KERNEL_FUSED2][1]) == 0
+    for k2 in (wdpm_amd.KERNEL_FUSED2, wdpm_amd.KERNEL_FUSED2W):
+        assert n_bit_diff(out[wdpm_amd.KERNEL_FUSED][0], out[k2][0]) == 0
+        assert n_bit_diff(out[wdpm_amd.KERNEL_FUSED][1], out[k2][1]) == 0

@@ -27,14 +27,16 @@ for ln, text in enumerate(lines, 1):
     if in_asm and t.startswith("s_waitcnt vmcnt"):
         inflight.clear()
         continue
-    regs = set()
-    for m in re.finditer(r"\bv\[(\d+):(\d+)\]", t):
-        regs.update(range(int(m.group(1)), int(m.group(2)) + 1))
-    for m in re.finditer(r"\bv(\d+)\b", t):
-        regs.add(int(m.group(1)))
+    regs = set()   # arch VGPR n -> n, accumulation VGPR n -> 1000 + n
+    for m in re.finditer(r"\b([va])\[(\d+):(\d+)\]", t):
+        base = 1000 if m.group(1) == "a" else 0
+        regs.update(range(base + int(m.group(2)), base + int(m.group(3)) + 1))
+    for m in re.finditer(r"\b([va])(\d+)\b", t):
+        regs.add((1000 if m.group(1) == "a" else 0) + int(m.group(2)))
     if in_asm and t.startswith("global_load"):
-        m = re.match(r"global_load_dwordx2 v\[(\d+):(\d+)\]", t)
-        dst = set(range(int(m.group(1)), int(m.group(2)) + 1))
+        m = re.match(r"global_load_dwordx2 ([va])\[(\d+):(\d+)\]", t)
+        base = 1000 if m.group(1) == "a" else 0
+        dst = set(range(base + int(m.group(2)), base + int(m.group(3)) + 1))
         for r in dst:
             if r in inflight:
                 print(f"line {ln}: load overwrites in-flight v{r} (loaded at line {inflight[r]})"); bad += 1

@@ -98,7 +98,19 @@ int wdpm_create(wdpm_ctx **out, const wdpm_params *p) {
   x->g.miss = p->missingvalue;
   if (p->module != WDPM_DRAIN) { x->g.dr = -1000000; x->g.dc = -1000000; }
   x->cells = (size_t)rows * x->g.ncp;
-  x->kernel = p->kernel == WDPM_KERNEL_AUTO ? WDPM_KERNEL_FUSED : p->kernel;
+  x->kernel = p->kernel;
+  if (x->kernel == WDPM_KERNEL_AUTO) {
+    /* The one-iteration kernel.  The two-iterations-per-launch kernels measured between -0.5 % and
+     * +8 % against it depending on slab shape and box (profiles/r01), not enough to make them the
+     * default; WDPM_KERNEL=pass|fused|fused2|fused2w selects one explicitly. */
+    x->kernel = WDPM_KERNEL_FUSED;
+    if (const char *e = getenv("WDPM_KERNEL")) {
+      if (!strcmp(e, "pass")) x->kernel = WDPM_KERNEL_PASS;
+      else if (!strcmp(e, "fused")) x->kernel = WDPM_KERNEL_FUSED;
+      else if (!strcmp(e, "fused2")) x->kernel = WDPM_KERNEL_FUSED2;
+      else if (!strcmp(e, "fused2w")) x->kernel = WDPM_KERNEL_FUSED2W;
+    }
+  }
   x->cur = 0;
   x->signed_zero_safe = false;
   x->launches = 0;
@@ -318,13 +330,18 @@ int wdpm_iterate(wdpm_ctx *x, int32_t n_iter) {
   else { HIP_TRY(hipEventCreate(&ep.a)); HIP_TRY(hipEventCreate(&ep.b)); }
   HIP_TRY(hipEventRecord(ep.a, x->stream));
   for (int it = 0; it < n_iter; it++) {
-    if (x->kernel == WDPM_KERNEL_FUSED2 && x->p.module != WDPM_DRAIN && n_iter - it >= 2) {
-      HIP_TRY(wdpm_launch_fused2(x->d_w[x->cur], x->d_w[x->cur ^ 1], x->d_dem, x->g, x->p.chunk_rows,
-                                 x->signed_zero_safe ? 1 : 0, x->stream));
+    if ((x->kernel == WDPM_KERNEL_FUSED2 || x->kernel == WDPM_KERNEL_FUSED2W) && x->p.module != WDPM_DRAIN &&
+        n_iter - it >= 2) {
+      if (x->kernel == WDPM_KERNEL_FUSED2W)
+        HIP_TRY(wdpm_launch_fused2w(x->d_w[x->cur], x->d_w[x->cur ^ 1], x->d_dem, x->g, x->p.chunk_rows,
+                                    x->signed_zero_safe ? 1 : 0, x->stream));
+      else
+        HIP_TRY(wdpm_launch_fused2(x->d_w[x->cur], x->d_w[x->cur ^ 1], x->d_dem, x->g, x->p.chunk_rows,
+                                   x->signed_zero_safe ? 1 : 0, x->stream));
       x->cur ^= 1;
       x->launches += 1;
       it++;                      /* this launch was two iterations */
-    } else if (x->kernel == WDPM_KERNEL_FUSED || x->kernel == WDPM_KERNEL_FUSED2) {
+    } else if (x->kernel == WDPM_KERNEL_FUSED || x->kernel == WDPM_KERNEL_FUSED2 || x->kernel == WDPM_KERNEL_FUSED2W) {
       HIP_TRY(wdpm_launch_fused(x->p.module, x->d_w[x->cur], x->d_w[x->cur ^ 1], x->d_dem, x->g, x->p.chunk_rows,
                                 x->signed_zero_safe ? 1 : 0, x->d_scal, x->stream));
       x->cur ^= 1;
