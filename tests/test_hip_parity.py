@@ -333,3 +333,23 @@ def test_two_iteration_kernel_full_size(hip):
     for k2 in (wdpm_amd.KERNEL_FUSED2, wdpm_amd.KERNEL_FUSED2W):
         assert n_bit_diff(out[wdpm_amd.KERNEL_FUSED][0], out[k2][0]) == 0
         assert n_bit_diff(out[wdpm_amd.KERNEL_FUSED][1], out[k2][1]) == 0
+
+
+def test_one_block_of_1000_iterations_at_8192(hip):
+    """a whole reference block (1000 iterations) at 8192^2: the one-iteration and the two-iteration
+    kernels end on identical bits and identical max diff; volume conserved; nothing negative"""
+    n, miss = 8192, -99999.0
+    dem = hip.synth_dem(n, n)
+    bd, bw = pad(dem, np.full((n, n), 0.1), miss)
+    del dem
+    kw = dict(module="add", nrows=n, ncols=n, missingvalue=miss)
+    res = {}
+    for kernel in (wdpm_amd.KERNEL_FUSED, wdpm_amd.KERNEL_FUSED2):
+        with hip.context(kernel=kernel, **kw) as c:
+            c.upload(bd, bw)
+            md = c.run_block(1000, 0.005 / 1000)
+            res[kernel] = (md, c.download_water())
+    (m1, w1), (m2, w2) = res[wdpm_amd.KERNEL_FUSED], res[wdpm_amd.KERNEL_FUSED2]
+    assert m1 == m2 and n_bit_diff(w1, w2) == 0
+    assert w1.min() >= 0.0
+    assert abs(float(w1.sum()) - 0.1 * n * n) <= 1e-9 * 0.1 * n * n
