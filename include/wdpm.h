@@ -98,6 +98,15 @@ int wdpm_begin_block(wdpm_ctx *ctx, double thres);
  *          (WDPMCL.c:1934-1964) for add and subtract; for drain runoffd() (:1967-2006) with the
  *          drain-centre gate (:1081-1082) and drain() (:1859-1897) after each iteration (:1089). */
 int wdpm_iterate(wdpm_ctx *ctx, int32_t n_iter);
+/* iterate, with the LAST iteration split so that a halo exchange can overlap it: the rows a
+ * neighbour needs — the first `top_rows` and the last `bottom_rows` rows of the slab (0 = none) — are
+ * produced first by two short launches on the context's stream; the remaining rows are produced by a
+ * third launch on an internal side stream.  Work the caller queues on the context's stream right
+ * after this call (the RCCL send/recv of the boundary rows) therefore starts as soon as the boundary
+ * rows exist; the library joins the side stream before its own next use of the raster.
+ * Results are identical to wdpm_iterate.  Add / subtract with the fused kernel; otherwise it simply
+ * calls wdpm_iterate. */
+int wdpm_iterate_overlapped(wdpm_ctx *ctx, int32_t n_iter, int32_t top_rows, int32_t bottom_rows);
 /* one colour pass (oi,oj in 1..3) — the unit the reference launches (WDPMCL.c:1187-1204);
  * exposed for golden-vector tests of single passes. */
 int wdpm_pass(wdpm_ctx *ctx, int32_t oi, int32_t oj);

@@ -353,3 +353,23 @@ def test_one_block_of_1000_iterations_at_8192(hip):
     assert m1 == m2 and n_bit_diff(w1, w2) == 0
     assert w1.min() >= 0.0
     assert abs(float(w1.sum()) - 0.1 * n * n) <= 1e-9 * 0.1 * n * n
+
+
+@pytest.mark.parametrize("R,C,top,bottom", [(300, 500, 33, 44), (200, 700, 0, 40), (150, 180, 25, 0), (90, 400, 30, 30),
+                                            (60, 200, 30, 30), (2079, 900, 33, 33)])
+def test_overlapped_iterate_equals_plain_iterate(hip, R, C, top, bottom):
+    """wdpm_iterate_overlapped: boundary rows first (two short launches), the interior on a side stream —
+    same bits as the single launch, whatever the windows; too-small interiors fall back to one launch"""
+    dem, water, miss = random_case(R + C, R, C)
+    bd, bw = pad(dem, water, miss)
+    kw = dict(module="add", nrows=R, ncols=C, missingvalue=miss)
+    with hip.context(**kw) as a, hip.context(**kw) as b:
+        a.upload(bd, bw)
+        b.upload(bd, bw)
+        for n in (1, 3, 4):
+            a.iterate(n)
+            b.iterate_overlapped(n, top, bottom)
+            # rows the neighbours need are complete on the context's stream alone; everything after a join
+            assert bits_equal(a.download_rows(0, max(top, 1)), b.download_rows(0, max(top, 1)))
+            assert n_bit_diff(a.download_water(), b.download_water()) == 0
+        assert a.run_block(5, 1e-6) == b.run_block(5, 1e-6)

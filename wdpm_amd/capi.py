@@ -52,6 +52,7 @@ SYMBOLS = {
     "wdpm_get_totaldrain": (C.c_int, [_vp, _dp]),
     "wdpm_begin_block": (C.c_int, [_vp, C.c_double]),
     "wdpm_iterate": (C.c_int, [_vp, C.c_int32]),
+    "wdpm_iterate_overlapped": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32]),
     "wdpm_pass": (C.c_int, [_vp, C.c_int32, C.c_int32]),
     "wdpm_drain_outlet": (C.c_int, [_vp]),
     "wdpm_max_diff": (C.c_int, [_vp, C.c_int32, C.c_int32, _dp]),
@@ -239,6 +240,9 @@ class Context:
 
     def iterate(self, n: int):
         self.lib.check(self.lib.dll.wdpm_iterate(self._h, n))
+
+    def iterate_overlapped(self, n: int, top_rows: int, bottom_rows: int):
+        self.lib.check(self.lib.dll.wdpm_iterate_overlapped(self._h, n, top_rows, bottom_rows))
 
     def single_pass(self, oi: int, oj: int):
         self.lib.check(self.lib.dll.wdpm_pass(self._h, oi, oj))

@@ -53,6 +53,10 @@ struct wdpm_ctx {
   std::vector<unsigned char> h_valid; /* bigdem > missingvalue per cell, kept only for wdpm_drain_stats */
   int kernel;                   /* resolved WDPM_KERNEL_* */
   bool signed_zero_safe;        /* a -0.0 depth was uploaded (or the caller asked): exact-zero stencil variant */
+  /* wdpm_iterate_overlapped: side stream for the interior launch and the event that joins it */
+  hipStream_t side;
+  hipEvent_t ev_fork, ev_join;
+  bool pending_join;
   /* stencil timing */
   std::vector<EventPair> pending;
   std::vector<EventPair> pool;
@@ -68,6 +72,10 @@ int wdpm_abi_version(void) { return WDPM_ABI_VERSION; }
 
 static int bind(wdpm_ctx *x) {
   HIP_TRY(hipSetDevice(x->p.device));
+  if (x->pending_join) {   /* the interior launch of the last overlapped iteration: order it before anything new */
+    HIP_TRY(hipStreamWaitEvent(x->stream, x->ev_join, 0));
+    x->pending_join = false;
+  }
   return 0;
 }
 
@@ -118,8 +126,12 @@ int wdpm_create(wdpm_ctx **out, const wdpm_params *p) {
   x->d_dem = x->d_w[0] = x->d_w[1] = x->d_old = nullptr;
   x->d_scal = nullptr; x->d_bits = nullptr; x->h_pin = nullptr;
   x->own_stream = true;
+  x->side = nullptr; x->ev_fork = nullptr; x->ev_join = nullptr; x->pending_join = false;
   const size_t bytes = x->cells * sizeof(double);
   hipError_t e = hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&x->side, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&x->ev_fork, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&x->ev_join, hipEventDisableTiming);
   if (e == hipSuccess) e = hipMalloc(&x->d_dem, bytes);
   /* + 64 doubles behind each water raster: the fused kernel's dump area for masked-out stores */
   if (e == hipSuccess) e = hipMalloc(&x->d_w[0], bytes + 64 * sizeof(double));
@@ -144,6 +156,9 @@ void wdpm_destroy(wdpm_ctx *x) {
   if (!x) return;
   (void)hipSetDevice(x->p.device);
   (void)hipStreamSynchronize(x->stream);
+  if (x->side) { (void)hipStreamSynchronize(x->side); (void)hipStreamDestroy(x->side); }
+  if (x->ev_fork) (void)hipEventDestroy(x->ev_fork);
+  if (x->ev_join) (void)hipEventDestroy(x->ev_join);
   for (auto &ep : x->pending) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
   for (auto &ep : x->pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
   (void)hipFree(x->d_dem); (void)hipFree(x->d_w[0]); (void)hipFree(x->d_w[1]); (void)hipFree(x->d_old);
@@ -154,7 +169,7 @@ void wdpm_destroy(wdpm_ctx *x) {
 }
 
 int wdpm_set_stream(wdpm_ctx *x, void *hip_stream) {
-  if (bind(x)) return 1;
+  if (bind(x)) return 1;   /* also joins a pending interior launch onto the old stream */
   HIP_TRY(hipStreamSynchronize(x->stream));
   if (x->own_stream && x->stream) HIP_TRY(hipStreamDestroy(x->stream));
   x->stream = (hipStream_t)hip_stream;
@@ -357,6 +372,40 @@ int wdpm_iterate(wdpm_ctx *x, int32_t n_iter) {
   }
   HIP_TRY(hipEventRecord(ep.b, x->stream));
   x->pending.push_back(ep);
+  return 0;
+}
+
+int wdpm_iterate_overlapped(wdpm_ctx *x, int32_t n_iter, int32_t top_rows, int32_t bottom_rows) {
+  if (n_iter < 0 || top_rows < 0 || bottom_rows < 0) return fail("wdpm_iterate_overlapped: negative argument");
+  const int rows = x->g.rows;
+  /* window boundaries: the top launch produces rows [0, t_last] with (t_last + 1) % 3 == 2, the bottom
+   * launch rows [b_first, rows-1] with b_first % 3 == 2, the interior launch the rows between */
+  int t_last = -1, b_first = rows;
+  if (top_rows > 0) { t_last = top_rows - 1; while ((t_last + 1) % 3 != 2) t_last++; }
+  if (bottom_rows > 0) { b_first = rows - bottom_rows; while (b_first % 3 != 2) b_first--; }
+  const bool usable = x->kernel == WDPM_KERNEL_FUSED && x->p.module != WDPM_DRAIN && n_iter > 0 &&
+                      (top_rows > 0 || bottom_rows > 0) && b_first - (t_last + 1) >= 24 && t_last < rows - 1 &&
+                      b_first >= 2;
+  if (!usable) return wdpm_iterate(x, n_iter);
+  if (n_iter > 1 && wdpm_iterate(x, n_iter - 1)) return 1;
+  if (bind(x)) return 1;
+  const double *w_in = x->d_w[x->cur];
+  double *w_out = x->d_w[x->cur ^ 1];
+  const int szs = x->signed_zero_safe ? 1 : 0;
+  HIP_TRY(hipEventRecord(x->ev_fork, x->stream));               /* w_in is complete here */
+  if (t_last >= 0)
+    HIP_TRY(wdpm_launch_fused_rows(x->p.module, w_in, w_out, x->d_dem, x->g, 0, t_last, x->p.chunk_rows, szs,
+                                   x->d_scal, x->stream));
+  if (b_first < rows)
+    HIP_TRY(wdpm_launch_fused_rows(x->p.module, w_in, w_out, x->d_dem, x->g, b_first - 2, rows - 1, x->p.chunk_rows,
+                                   szs, x->d_scal, x->stream));
+  HIP_TRY(hipStreamWaitEvent(x->side, x->ev_fork, 0));
+  HIP_TRY(wdpm_launch_fused_rows(x->p.module, w_in, w_out, x->d_dem, x->g, t_last >= 0 ? t_last - 1 : 0,
+                                 b_first < rows ? b_first - 1 : rows - 1, x->p.chunk_rows, szs, x->d_scal, x->side));
+  HIP_TRY(hipEventRecord(x->ev_join, x->side));
+  x->pending_join = true;
+  x->cur ^= 1;
+  x->launches += 3;
   return 0;
 }
 

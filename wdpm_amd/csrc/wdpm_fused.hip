@@ -176,7 +176,8 @@ template <int MODULE, bool SZ_SAFE>
 __global__ void __launch_bounds__(256, WDPM_FUSED_MIN_WAVES)
 fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout,
                        const double *__restrict__ dem, const SlabGeom g, const int nstrips,
-                       const int nitems, const int H, double *__restrict__ totaldrain) {
+                       const int nitems, const int H, const int A0, const int out_last,
+                       double *__restrict__ totaldrain) {
   const int lane = threadIdx.x & 63;
   // Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2; placement is only a
   // speed matter, never correctness): give each XCD a contiguous run of work items so that the
@@ -192,11 +193,12 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
   const int c0 = kStripOut * strip;
   const int oc_lo = strip == 0 ? 0 : c0 + kHaloL;
   const int oc_hi = c0 + kStripIn - 1 - kHaloR;
-  const int A = H * chunk;
+  // a launch produces the rows [A0 + 2 (0 when A0 == 0), out_last] of the slab; A0 % 3 == 0
+  const int A = A0 + H * chunk;
   const int nsteps = H / 3 + 2;
-  const int or_lo = chunk == 0 ? 0 : A + 2;
-  int or_hi = H * (chunk + 1) + 1;
-  if (or_hi > g.rows - 1) or_hi = g.rows - 1;
+  const int or_lo = A == 0 ? 0 : A + 2;
+  int or_hi = A0 + H * (chunk + 1) + 1;
+  if (or_hi > out_last) or_hi = out_last;
 
   const int colb = c0 + 3 * lane;
   // store side: after the LDS transpose, store instruction k = 0,1,2 writes the strip-relative
@@ -943,8 +945,17 @@ hipError_t wdpm_launch_fused2w(const double *w_in, double *w_out, const double *
 hipError_t wdpm_launch_fused(int module, const double *w_in, double *w_out, const double *dem,
                              const SlabGeom &g, int chunk_rows, int signed_zero_safe, double *totaldrain,
                              hipStream_t s) {
+  return wdpm_launch_fused_rows(module, w_in, w_out, dem, g, 0, g.rows - 1, chunk_rows, signed_zero_safe,
+                                totaldrain, s);
+}
+
+/* one iteration restricted to the output rows [A0 + 2 (0 when A0 == 0), out_last]; A0 % 3 == 0 */
+hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out, const double *dem,
+                                  const SlabGeom &g, int A0, int out_last, int chunk_rows,
+                                  int signed_zero_safe, double *totaldrain, hipStream_t s) {
   hipError_t e = dpp_selfcheck(s);
   if (e != hipSuccess) return e;
+  if (A0 < 0 || A0 % 3 != 0 || out_last > g.rows - 1 || out_last < A0) return hipErrorInvalidValue;
   int nstrips = 1;
   if (g.ncp > kStripIn - kHaloR) nstrips = (g.ncp - (kStripIn - kHaloR) + kStripOut - 1) / kStripOut + 1;
   const bool fast = module != 2 && !signed_zero_safe;
@@ -959,17 +970,18 @@ hipError_t wdpm_launch_fused(int module, const double *w_in, double *w_out, cons
     if (pct < 0) { const char *e = getenv("WDPM_FILL_PERCENT"); pct = e ? atoi(e) : 50; }
     if (pct > 0 && pct < 100) slots = slots * pct / 100;
   }
-  const int H = pick_chunk_rows(g.rows, nstrips, chunk_rows, slots);
-  // chunk i stores rows [H*i+2 (0 for i=0), H*(i+1)+1]; the last must reach row rows-1
-  int nchunks = (g.rows - 2 + H - 1) / H;
+  const int wrows = out_last - A0 + 1;                       // rows of this launch's window
+  const int H = pick_chunk_rows(wrows, nstrips, chunk_rows, slots);
+  // chunk i stores rows [A0+H*i+2 (0 for A0+H*i = 0), A0+H*(i+1)+1]; the last must reach out_last
+  int nchunks = (out_last - A0 - 1 + H - 1) / H;
   if (nchunks < 1) nchunks = 1;
   const int nitems = nstrips * nchunks;
   const dim3 grid(((nitems + 3) / 4 + 7) / 8 * 8), block(256);   // multiple of 8: see the XCD remap
   if (module == 2)
-    hipLaunchKernelGGL((fused_iteration_kernel<2, true>), grid, block, 0, s, w_in, w_out, dem, g, nstrips, nitems, H, totaldrain);
+    hipLaunchKernelGGL((fused_iteration_kernel<2, true>), grid, block, 0, s, w_in, w_out, dem, g, nstrips, nitems, H, A0, out_last, totaldrain);
   else if (fast)
-    hipLaunchKernelGGL((fused_iteration_kernel<0, false>), grid, block, 0, s, w_in, w_out, dem, g, nstrips, nitems, H, totaldrain);
+    hipLaunchKernelGGL((fused_iteration_kernel<0, false>), grid, block, 0, s, w_in, w_out, dem, g, nstrips, nitems, H, A0, out_last, totaldrain);
   else
-    hipLaunchKernelGGL((fused_iteration_kernel<0, true>), grid, block, 0, s, w_in, w_out, dem, g, nstrips, nitems, H, totaldrain);
+    hipLaunchKernelGGL((fused_iteration_kernel<0, true>), grid, block, 0, s, w_in, w_out, dem, g, nstrips, nitems, H, A0, out_last, totaldrain);
   return hipGetLastError();
 }

@@ -35,6 +35,9 @@ hipError_t wdpm_launch_fused2(const double *w_in, double *w_out, const double *d
                               int chunk_rows, int signed_zero_safe, hipStream_t s);
 hipError_t wdpm_launch_fused2w(const double *w_in, double *w_out, const double *dem, const SlabGeom &g,
                                int chunk_rows, int signed_zero_safe, hipStream_t s);
+hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out, const double *dem,
+                                  const SlabGeom &g, int A0, int out_last, int chunk_rows,
+                                  int signed_zero_safe, double *totaldrain, hipStream_t s);
 /* *flag |= 1 if any of the n doubles at p is -0.0 */
 hipError_t wdpm_launch_scan_negzero(const double *p, size_t n, unsigned long long *flag, hipStream_t s);
 /* drain() (WDPMCL.c:1859-1897) on the device */

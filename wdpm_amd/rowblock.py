@@ -148,7 +148,7 @@ class RowBlockSolver:
 
     def __init__(self, lib: Lib, module, nrows: int, ncols: int, missingvalue: float, rank: int = 0,
                  nranks: int = 1, exchange_every: int = 4, transport=None, dist=None, drainrow: int = 0,
-                 draincol: int = 0, fallback_transport=None, **ctx_kw):
+                 draincol: int = 0, fallback_transport=None, overlap: bool = True, **ctx_kw):
         self.rank, self.nranks, self.k = rank, nranks, max(1, exchange_every)
         self.slabs = partition(nrows, nranks, self.k)
         self.slab = self.slabs[rank]
@@ -160,6 +160,7 @@ class RowBlockSolver:
                                drainrow=drainrow, draincol=draincol, slab_row0=s.row0,
                                slab_rows=s.rows if nranks > 1 else 0, **ctx_kw)
         self.module = self.ctx.module
+        self.overlap = overlap and nranks > 1
         self._since_exchange = 0
         # drain module: the rank whose OWNED rows hold the outlet has the raster's totaldrain
         self.drain_owner = next((sl.rank for sl in self.slabs if sl.own_lo <= drainrow <= sl.own_hi), 0)
@@ -231,7 +232,15 @@ class RowBlockSolver:
                 self.exchange()
                 room = self.k
             step = min(room, n_iter - done)
-            self.ctx.iterate(step)
+            if self.overlap and step == room:
+                # this step ends a group and an exchange follows: produce the rows the neighbours
+                # need first, so that the send/recv overlaps the rest of the last iteration
+                s = self.slab
+                top = s.lo + self.slabs[s.rank - 1].down if s.rank > 0 else 0
+                bottom = s.rows - (s.hi - self.slabs[s.rank + 1].up) if s.rank < s.nranks - 1 else 0
+                self.ctx.iterate_overlapped(step, top, bottom)
+            else:
+                self.ctx.iterate(step)
             done += step
             self._since_exchange += step
 
