@@ -6,9 +6,10 @@
  * Design (DESIGN.md §4 has the derivation and the numpy model tests/fused_model.py checks the
  * schedule against the oracle):
  *
- *  - A wave64 is the unit of work; waves never synchronise with each other (no LDS, no barriers).
- *    Lane m owns raster columns c0+3m .. c0+3m+2, so a wave covers a 192-column strip and a
- *    64-lane row load/store is one contiguous 1536-byte segment.
+ *  - A wave64 is the unit of work; waves never synchronise with each other (no barriers; LDS is
+ *    only a wave-private transpose buffer for the stores).  Lane m owns raster columns
+ *    c0+3m .. c0+3m+2, so a wave covers a 192-column strip and a 64-lane row load is one
+ *    contiguous 1536-byte segment; one wave per SIMD already saturates HBM.
  *  - The wave marches down a chunk of rows with a 7-row window held in registers (dem + water,
  *    3 columns per lane).  Each step loads 3 new rows and applies, in this order, row alignment
  *    oi=1 to rows 3n..3n+2, oi=2 to rows 3n-2..3n, oi=3 to rows 3n-4..3n-2 — a skew that respects
@@ -25,7 +26,12 @@
  *    neighbour this makes ht_diff -inf/NaN, so `ht_diff > 0` is false with no extra test
  *    (WDPMCL.c:1944); as a centre the gate `dem < +inf` replaces `bigdem > missingvalue` (:1099).
  *
+ *  - Memory operations are unconditional and fixed in number per step (prefetch by inline-asm
+ *    loads one step ahead, exact s_waitcnt; stores transposed through LDS to 512-byte contiguous
+ *    non-temporal writes, issued at the top of the following step).
+ *
  * Results are bit-identical to the serial reference: same operands, same order, fp64, no FMA.
+ * The file also holds the opt-in two-iterations-per-launch kernels (fused2, fused2w).
  */
 #include "wdpm_kernels.h"
 #include "wdpm_stencil.h"
