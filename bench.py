@@ -56,7 +56,7 @@ def measured_traffic(n, world, kernel):
     return None
 
 
-def cpu_baseline(n=4096, iters=24):
+def cpu_baseline(n=4096, iters=32):
     """The CPU oracle (bit-equal port of the reference's serial path) timed on one host core on a
     bounded sample of the same workload.  A reported baseline, never the product path."""
     import subprocess

@@ -253,9 +253,9 @@ int wdpm_copy_rows(wdpm_ctx *dst, int32_t dst_row, wdpm_ctx *src, int32_t src_ro
   /* everything queued on the source must have produced the rows, everything queued on the
    * destination must be done with the rows being overwritten; the copy itself is synchronous
    * with respect to the host so that the caller may launch on either context afterwards */
-  HIP_TRY(hipSetDevice(src->p.device));
+  if (bind(src)) return 1;                       /* also joins a pending overlapped interior launch */
   HIP_TRY(hipStreamSynchronize(src->stream));
-  HIP_TRY(hipSetDevice(dst->p.device));
+  if (bind(dst)) return 1;
   HIP_TRY(hipStreamSynchronize(dst->stream));
   const size_t bytes = (size_t)nrows * src->g.ncp * sizeof(double);
   double *d = dst->d_w[dst->cur] + (size_t)dst_row * dst->g.ncp;
