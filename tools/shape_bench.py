@@ -5,11 +5,13 @@ import numpy as np
 sys.path.insert(0, ".")
 import wdpm_amd
 R, C = int(sys.argv[1]), int(sys.argv[2]); iters = int(sys.argv[3]) if len(sys.argv) > 3 else 200
+only = sys.argv[4].split(",") if len(sys.argv) > 4 else None
 lib = wdpm_amd.load_hip()
 rng = np.random.default_rng(1)
 bd = np.full((R + 2, C + 2), -99999.0); bd[1:-1, 1:-1] = 500 + rng.random((R, C))
 bw = np.where(bd > -99999.0, 0.1, 0.0)
 for name, k in (("fused", wdpm_amd.KERNEL_FUSED), ("fused2", wdpm_amd.KERNEL_FUSED2), ("fused2w", wdpm_amd.KERNEL_FUSED2W)):
+    if only and name not in only: continue
     with lib.context(module="add", nrows=R, ncols=C, missingvalue=-99999.0, kernel=k) as c:
         c.upload(bd, bw); c.iterate(20); c.synchronize(); c.timing_reset()
         t = time.perf_counter(); c.iterate(iters); c.synchronize(); dt = time.perf_counter() - t

@@ -341,9 +341,14 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
       store_rows(A + 3 * (n - 1) - 4);
 
       const int rbase = A + 3 * n - 4;                 // slab row of window slot 0
+#ifndef WDPM_ABLATE_COMPUTE                            /* timing experiments only: memory pattern alone */
       stage<MODULE, SZ_SAFE, 4>(W, D, rbase + 4, g.dr, cdr, ds);   // oi = 1 on rows 3n   .. 3n+2
       stage<MODULE, SZ_SAFE, 2>(W, D, rbase + 2, g.dr, cdr, ds);   // oi = 2 on rows 3n-2 .. 3n
       stage<MODULE, SZ_SAFE, 0>(W, D, rbase + 0, g.dr, cdr, ds);   // oi = 3 on rows 3n-4 .. 3n-2
+#else
+#pragma unroll
+      for (int j = 0; j < 3; j++) W[0][j] += D[0][j] + D[1][j] + D[2][j];   // keep the dem loads alive
+#endif
 
       // rows 3n-4 .. 3n-2 have now seen all nine passes.  The wave transposes each row through its
       // private LDS slice (no barrier: a wave's LDS operations complete in order) so that every
