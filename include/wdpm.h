@@ -174,6 +174,13 @@ enum { WDPM_OPT_SIGNED_ZERO_SAFE = 1 };
 int wdpm_get_option(wdpm_ctx *ctx, int32_t key, int64_t *value);
 int wdpm_set_option(wdpm_ctx *ctx, int32_t key, int64_t value);
 
+/* -- host staging memory for whole rasters.  The HIP back-end returns page-locked memory, so that
+ * wdpm_upload / wdpm_download_water / the scratch checkpoint move at PCIe rate instead of through a
+ * pageable bounce buffer (the reference maps its host arrays with CL_MEM_USE_HOST_PTR,
+ * src/WDPMCL.c:1138-1141); the CPU restatement returns malloc memory.  Release with wdpm_host_free. */
+int wdpm_host_alloc(size_t bytes, void **ptr);
+void wdpm_host_free(void *ptr);
+
 /* -- synthetic DEM generator: integer-seeded, identical on every
  * host.  Writes an n x n UNPADDED row-major raster. */
 int wdpm_synth_dem(int32_t n, uint64_t seed, double *dem);

@@ -133,6 +133,49 @@ def multi_device(exe, golden, cwd, devices):
         assert file_sha(os.path.join(cwd, outfile)) == g["out_sha256"]
 
 
+def lossless_resume(exe, golden, cwd):
+    """with WDPM_SCRATCH_BINARY=1 a checkpoint also leaves <scratch>.f64 and a resumed
+    run continues bit-for-bit: 2000 iterations + checkpoint + 1000 resumed == 3000 uninterrupted (the
+    reference's own golden output), which the 1e-6 m text scratch alone cannot reproduce."""
+    g = golden["cfg1_add100_k3000"]
+    env = dict(os.environ, WDPM_SCRATCH_BINARY="1")
+    args = list(g["args"])
+    args[4] = "ck.asc"
+    p = subprocess.run([exe] + args, cwd=cwd, capture_output=True, text=True, timeout=1500, env=env)
+    assert p.returncode == 0, p.stderr
+    assert file_sha(os.path.join(cwd, "a100.asc")) == g["out_sha256"]          # checkpointing changes nothing
+    assert os.path.exists(os.path.join(cwd, "ck.asc")) and os.path.exists(os.path.join(cwd, "ck.asc.f64"))
+    assert not os.path.exists(os.path.join(cwd, "ck.asc.f64.tmp"))
+    os.remove(os.path.join(cwd, "a100.asc"))
+    args[-1] = "1000"                                                          # the checkpoint holds k = 2000
+    p = subprocess.run([exe] + args, cwd=cwd, capture_output=True, text=True, timeout=1500, env=env)
+    assert p.returncode == 0, p.stderr
+    assert "full-precision checkpoint" in p.stderr
+    blocks, _ = parse_report(p.stdout)
+    assert [b[1:] for b in blocks] == [g["blocks"][2][1:]]                      # same max-diff as block 3 of the long run
+    assert file_sha(os.path.join(cwd, "a100.asc")) == g["out_sha256"]
+    # a sidecar that belongs to another checkpoint is ignored (it disagrees with the text scratch)
+    import numpy as np
+    raw = np.fromfile(os.path.join(cwd, "ck.asc.f64"), dtype=np.uint8)
+    body = raw[32:].view(np.float64).copy()
+    body[body > 0] += 1e-3
+    with open(os.path.join(cwd, "ck.asc.f64"), "wb") as f:
+        f.write(raw[:32].tobytes() + body.tobytes())
+    args[4], args[3] = "ck.asc", "other.asc"
+    shutil.copy(os.path.join(cwd, "ck.asc"), os.path.join(cwd, "keep.asc"))
+    p = subprocess.run([exe] + args, cwd=cwd, capture_output=True, text=True, timeout=1500, env=env)
+    assert p.returncode == 0 and "ignored" in p.stderr
+
+
+def test_cli_lossless_checkpoint_resume_on_oracle_backend(workdir, golden):
+    lossless_resume(ORACLE_CLI, golden, workdir)
+
+
+@pytest.mark.gpu
+def test_hip_cli_lossless_checkpoint_resume(workdir, golden):
+    lossless_resume(HIP_CLI, golden, workdir)
+
+
 def test_cli_three_contexts_on_oracle_backend(workdir, golden):
     multi_device(ORACLE_CLI, golden, workdir, "0,0,0")
 

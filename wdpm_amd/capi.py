@@ -78,6 +78,8 @@ SYMBOLS = {
     "wdpm_get_option": (C.c_int, [_vp, C.c_int32, C.POINTER(C.c_int64)]),
     "wdpm_set_option": (C.c_int, [_vp, C.c_int32, C.c_int64]),
     "wdpm_synth_dem": (C.c_int, [C.c_int32, C.c_uint64, _vp]),
+    "wdpm_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(_vp)]),
+    "wdpm_host_free": (None, [_vp]),
 }
 
 

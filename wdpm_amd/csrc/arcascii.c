@@ -333,3 +333,40 @@ int asc_write_grid(const char *path, const asc_header *h, int nrows, int ncols, 
   if (fclose(f) != 0) rc = 1;
   return rc;
 }
+
+static const char kF64Magic[8] = {'W', 'D', 'P', 'M', 'F', '6', '4', '\n'};
+
+int asc_write_f64(const char *path, int nrows, int ncols, const double *src) {
+  const size_t plen = strlen(path);
+  char *tmp = (char *)malloc(plen + 5);
+  if (!tmp) return 1;
+  memcpy(tmp, path, plen);
+  memcpy(tmp + plen, ".tmp", 5);
+  FILE *f = fopen(tmp, "wb");
+  if (!f) { free(tmp); return 1; }
+  const int64_t dims[3] = {nrows, ncols, 0};
+  const size_t n = (size_t)nrows * ncols;
+  int rc = fwrite(kF64Magic, 1, 8, f) != 8 || fwrite(dims, sizeof(int64_t), 3, f) != 3 || fwrite(src, sizeof(double), n, f) != n;
+  if (fclose(f) != 0) rc = 1;
+  if (!rc && rename(tmp, path) != 0) rc = 1;
+  if (rc) remove(tmp);
+  free(tmp);
+  return rc;
+}
+
+int asc_read_f64(const char *path, int nrows, int ncols, double *dst) {
+  FILE *f = fopen(path, "rb");
+  if (!f) return 1;
+  char magic[8];
+  int64_t dims[3];
+  const size_t n = (size_t)nrows * ncols;
+  int rc = fread(magic, 1, 8, f) != 8 || memcmp(magic, kF64Magic, 8) != 0 || fread(dims, sizeof(int64_t), 3, f) != 3 ||
+           dims[0] != nrows || dims[1] != ncols;
+  if (!rc) {
+    /* complete file of exactly this size? (never half-fill dst) */
+    if (fseek(f, 0, SEEK_END) != 0 || ftell(f) != (long)(32 + n * sizeof(double)) || fseek(f, 32, SEEK_SET) != 0) rc = 1;
+  }
+  if (!rc && fread(dst, sizeof(double), n, f) != n) rc = 1;
+  fclose(f);
+  return rc;
+}

@@ -28,6 +28,13 @@ int asc_read_grid(const char *path, int nrows, int ncols, double *dst);
 /* write header + grid: "%s %d" / "%s %14.6f" / "%s %9.6f" lines and "%f " per cell */
 int asc_write_grid(const char *path, const asc_header *h, int nrows, int ncols, const double *src);
 
+/* lossless side-format of a checkpoint (the ASCII scratch keeps 1e-6 m): a 32-byte
+ * header {"WDPMF64\n", int64 nrows, int64 ncols, int64 0} followed by nrows*ncols host-order doubles.
+ * Written to "<path>.tmp" and renamed, so a reader never sees a torn file.  asc_read_f64 fills dst
+ * and returns 0 only if the file exists, is complete and has exactly these dimensions. */
+int asc_write_f64(const char *path, int nrows, int ncols, const double *src);
+int asc_read_f64(const char *path, int nrows, int ncols, double *dst);
+
 /* exact fast paths behind the reader/writer (exposed for tests): the characters of
  * printf("%f", x) without NUL (returns their count; out needs >= 340 bytes), and strtod for plain
  * decimal numbers */

@@ -50,6 +50,8 @@ struct wdpm_ctx {
   double *d_scal;               /* [0] totaldrain, [1] olddrain */
   unsigned long long *d_bits;   /* max-diff reduction cell */
   double *h_pin;                /* pinned staging: 4 doubles */
+  double *h_sum[2];             /* pinned chunk buffers of wdpm_volume_partial (allocated on first use) */
+  hipEvent_t ev_sum[2];
   std::vector<unsigned char> h_valid; /* bigdem > missingvalue per cell, kept only for wdpm_drain_stats */
   int kernel;                   /* resolved WDPM_KERNEL_* */
   bool signed_zero_safe;        /* a -0.0 depth was uploaded (or the caller asked): exact-zero stencil variant */
@@ -125,6 +127,7 @@ int wdpm_create(wdpm_ctx **out, const wdpm_params *p) {
   x->ms = 0.0;
   x->d_dem = x->d_w[0] = x->d_w[1] = x->d_old = nullptr;
   x->d_scal = nullptr; x->d_bits = nullptr; x->h_pin = nullptr;
+  x->h_sum[0] = x->h_sum[1] = nullptr; x->ev_sum[0] = x->ev_sum[1] = nullptr;
   x->own_stream = true;
   x->side = nullptr; x->ev_fork = nullptr; x->ev_join = nullptr; x->pending_join = false;
   const size_t bytes = x->cells * sizeof(double);
@@ -164,6 +167,10 @@ void wdpm_destroy(wdpm_ctx *x) {
   (void)hipFree(x->d_dem); (void)hipFree(x->d_w[0]); (void)hipFree(x->d_w[1]); (void)hipFree(x->d_old);
   (void)hipFree(x->d_scal); (void)hipFree(x->d_bits);
   if (x->h_pin) (void)hipHostFree(x->h_pin);
+  for (int i = 0; i < 2; i++) {
+    if (x->h_sum[i]) (void)hipHostFree(x->h_sum[i]);
+    if (x->ev_sum[i]) (void)hipEventDestroy(x->ev_sum[i]);
+  }
   if (x->own_stream && x->stream) (void)hipStreamDestroy(x->stream);
   delete x;
 }
@@ -438,16 +445,49 @@ int wdpm_volume_partial(wdpm_ctx *x, int32_t row_lo, int32_t row_hi, double star
   if (x->h_valid.size() != x->cells) return fail("wdpm_volume_partial: no DEM has been uploaded to this drain context");
   if (bind(x)) return 1;
   const size_t first = (size_t)row_lo * x->g.ncp, n = (size_t)(row_hi - row_lo) * x->g.ncp;
-  std::vector<double> w(n);
-  if (n) {
-    HIP_TRY(hipMemcpyAsync(w.data(), x->d_w[x->cur] + first, n * sizeof(double), hipMemcpyDeviceToHost, x->stream));
-    HIP_TRY(hipStreamSynchronize(x->stream));
+  /* the sum must be the reference's sequential one (a parallel sum rounds differently), so the host
+   * adds while the next chunk is on its way: two page-locked 8-MiB buffers, copies on the side
+   * stream behind everything queued on the context's stream */
+  const size_t chunk = (size_t)1 << 20;
+  if (!x->h_sum[0]) {
+    HIP_TRY(hipHostMalloc((void **)&x->h_sum[0], chunk * sizeof(double), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **)&x->h_sum[1], chunk * sizeof(double), hipHostMallocDefault));
+    HIP_TRY(hipEventCreateWithFlags(&x->ev_sum[0], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&x->ev_sum[1], hipEventDisableTiming));
   }
+  HIP_TRY(hipEventRecord(x->ev_fork, x->stream));
+  HIP_TRY(hipStreamWaitEvent(x->side, x->ev_fork, 0));
+  const double *src = x->d_w[x->cur] + first;
+  const size_t nchunks = (n + chunk - 1) / chunk;
+  auto fetch = [&](size_t c) -> hipError_t {
+    const size_t off = c * chunk, len = n - off < chunk ? n - off : chunk;
+    hipError_t e = hipMemcpyAsync(x->h_sum[c & 1], src + off, len * sizeof(double), hipMemcpyDeviceToHost, x->side);
+    return e == hipSuccess ? hipEventRecord(x->ev_sum[c & 1], x->side) : e;
+  };
   double s = start;
-  for (size_t i = 0; i < n; i++)
-    if (x->h_valid[first + i]) s += w[i];
+  if (nchunks) HIP_TRY(fetch(0));
+  for (size_t c = 0; c < nchunks; c++) {
+    HIP_TRY(hipEventSynchronize(x->ev_sum[c & 1]));
+    if (c + 1 < nchunks) HIP_TRY(fetch(c + 1));          /* the other buffer: summed one trip ago */
+    const size_t off = c * chunk, len = n - off < chunk ? n - off : chunk;
+    const double *w = x->h_sum[c & 1];
+    const unsigned char *ok = x->h_valid.data() + first + off;
+    for (size_t i = 0; i < len; i++)
+      if (ok[i]) s += w[i];
+  }
   *sum = s;
   return 0;
+}
+
+int wdpm_host_alloc(size_t bytes, void **ptr) {
+  if (!ptr) return fail("wdpm_host_alloc: null argument");
+  *ptr = nullptr;
+  HIP_TRY(hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocPortable));
+  return 0;
+}
+
+void wdpm_host_free(void *ptr) {
+  if (ptr) (void)hipHostFree(ptr);
 }
 
 int wdpm_run_block(wdpm_ctx *x, int32_t n_iter, double thres, double *max_diff) {

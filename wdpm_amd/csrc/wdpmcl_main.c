@@ -363,6 +363,40 @@ static void announce_no_scratch(int module) {
   printf("%s\n", "           ");
 }
 
+/* WDPM_SCRATCH_BINARY=1: every checkpoint also leaves "<scratch>.f64", the same state in full
+ * precision (arcascii.h), and a resume prefers it when it agrees with the ASCII scratch to the
+ * 1e-6 m the text keeps (i.e. when it is the same checkpoint): the resumed run then continues
+ * bit-for-bit where the interrupted one stopped, which the reference's text scratch cannot do. */
+static int scratch_binary_enabled(void) {
+  const char *e = getenv("WDPM_SCRATCH_BINARY");
+  return e && atoi(e) != 0;
+}
+
+static char *sidecar_name(const char *scratch) {
+  char *p = (char *)malloc(strlen(scratch) + 5);
+  if (p) sprintf(p, "%s.f64", scratch);
+  return p;
+}
+
+static void prefer_lossless_scratch(const run_config *c, raster_state *s) {
+  if (!scratch_binary_enabled()) return;
+  char *side = sidecar_name(c->scratch);
+  const size_t n = (size_t)s->R * s->C;
+  double *full = (double *)malloc(n * sizeof(double));
+  if (side && full && asc_read_f64(side, s->R, s->C, full) == 0) {
+    size_t bad = 0;
+    for (size_t i = 0; i < n; i++) bad += !(fabs(full[i] - s->water[i]) <= 5.0000001e-7);
+    if (bad == 0) {
+      memcpy(s->water, full, n * sizeof(double));
+      fprintf(stderr, "WDPMCL: resuming from the full-precision checkpoint %s\n", side);
+    } else {
+      fprintf(stderr, "WDPMCL: %s does not match the scratch file (%zu cells differ): ignored\n", side, bad);
+    }
+  }
+  free(full);
+  free(side);
+}
+
 static void setup_module(const run_config *c, raster_state *s) {
   const int have_scratch_name = !is_null_name(c->scratch);
   int resumed = 0;
@@ -373,6 +407,7 @@ static void setup_module(const run_config *c, raster_state *s) {
       printf("%s\n", "           ");
       printf("%30s\n", "Scratch file found");
       asc_read_grid(c->scratch, s->R, s->C, s->water);
+      prefer_lossless_scratch(c, s);
       resumed = 1;
     } else {
       announce_no_scratch(c->module);
@@ -462,12 +497,18 @@ typedef struct {
   pthread_mutex_t mu;
   pthread_cond_t cv;
   const char *path;
+  char *sidecar;     /* "<path>.f64" when WDPM_SCRATCH_BINARY is set, else NULL */
   const asc_header *hdr;
   int R, C;
   double *pending;   /* newest state not yet picked up by the writer, or NULL */
   double *spare;     /* buffer the producer may fill next */
   int busy, quit, started;
 } scratch_writer;
+
+static void scratch_write_now(const scratch_writer *w, const double *water) {
+  if (w->sidecar) asc_write_f64(w->sidecar, w->R, w->C, water);
+  asc_write_grid(w->path, w->hdr, w->R, w->C, water);
+}
 
 static void *scratch_main(void *arg) {
   scratch_writer *w = (scratch_writer *)arg;
@@ -479,7 +520,7 @@ static void *scratch_main(void *arg) {
     w->pending = NULL;
     w->busy = 1;
     pthread_mutex_unlock(&w->mu);
-    asc_write_grid(w->path, w->hdr, w->R, w->C, job);
+    scratch_write_now(w, job);
     pthread_mutex_lock(&w->mu);
     w->busy = 0;
     if (!w->spare) w->spare = job; else free(job);
@@ -494,20 +535,21 @@ static void scratch_start(scratch_writer *w, const char *path, const asc_header 
   pthread_mutex_init(&w->mu, NULL);
   pthread_cond_init(&w->cv, NULL);
   w->path = path; w->hdr = hdr; w->R = R; w->C = C;
+  w->sidecar = scratch_binary_enabled() ? sidecar_name(path) : NULL;
   w->started = pthread_create(&w->thread, NULL, scratch_main, w) == 0;
 }
 
 /* hand over a copy of the un-padded raster (takes the cells from `water`) */
 static void scratch_submit(scratch_writer *w, const double *water) {
   const size_t bytes = (size_t)w->R * w->C * sizeof(double);
-  if (!w->started) { asc_write_grid(w->path, w->hdr, w->R, w->C, water); return; }
+  if (!w->started) { scratch_write_now(w, water); return; }
   pthread_mutex_lock(&w->mu);
   double *buf = w->pending ? w->pending : w->spare;    /* supersede an unwritten older state */
   if (buf == w->spare) w->spare = NULL;
   w->pending = NULL;
   pthread_mutex_unlock(&w->mu);
   if (!buf) buf = (double *)malloc(bytes);
-  if (!buf) { asc_write_grid(w->path, w->hdr, w->R, w->C, water); return; }
+  if (!buf) { scratch_write_now(w, water); return; }
   memcpy(buf, water, bytes);
   pthread_mutex_lock(&w->mu);
   w->pending = buf;
@@ -516,7 +558,7 @@ static void scratch_submit(scratch_writer *w, const double *water) {
 }
 
 static void scratch_finish(scratch_writer *w) {
-  if (!w->started) return;
+  if (!w->started) { free(w->sidecar); return; }
   pthread_mutex_lock(&w->mu);
   w->quit = 1;
   pthread_cond_broadcast(&w->cv);
@@ -524,6 +566,21 @@ static void scratch_finish(scratch_writer *w) {
   pthread_join(w->thread, NULL);
   free(w->spare);
   free(w->pending);
+  free(w->sidecar);
+}
+
+/* WDPM_TIMING=1: wall time of each phase of the run on stderr (never on stdout: the report stays
+ * the reference's) */
+static void phase(const char *name) {
+  static struct timeval last;
+  static int on = -1;
+  if (on < 0) {
+    on = getenv("WDPM_TIMING") && atoi(getenv("WDPM_TIMING")) != 0;
+    gettimeofday(&last, NULL);
+  }
+  if (!on || !name) return;
+  fprintf(stderr, "WDPMCL timing: %-28s %8.3f s\n", name, seconds_since(&last));
+  gettimeofday(&last, NULL);
 }
 
 #define ABI_TRY(call)                                                      \
@@ -540,6 +597,7 @@ int main(int argc, char **argv) {
   parse_command_line(argc, argv, &cfg);
   echo_parameters(&cfg);
 
+  phase(NULL);
   asc_header hdr;
   if (asc_read_header(cfg.dem, &hdr) != 0) {
     fprintf(stderr, "WDPMCL: cannot read DEM file %s\n", cfg.dem);
@@ -569,19 +627,33 @@ int main(int argc, char **argv) {
   const size_t ncell = (size_t)st.R * st.C, nbig = (size_t)(st.R + 2) * (st.C + 2);
   st.dem = (double *)calloc(ncell, sizeof(double));
   st.water = (double *)calloc(ncell, sizeof(double));
-  st.bigdem = (double *)calloc(nbig, sizeof(double));
-  st.bigwater = (double *)calloc(nbig, sizeof(double));
+  /* the two rasters that travel to and from the device: staging memory from the library
+   * (page-locked on the HIP back-end); WDPM_PINNED=0 keeps them in ordinary memory */
+  const int pinned = !(getenv("WDPM_PINNED") && atoi(getenv("WDPM_PINNED")) == 0);
+  if (pinned) {
+    void *a = NULL, *b = NULL;
+    ABI_TRY(wdpm_host_alloc(nbig * sizeof(double), &a));
+    ABI_TRY(wdpm_host_alloc(nbig * sizeof(double), &b));
+    st.bigdem = (double *)a;
+    st.bigwater = (double *)b;
+  } else {
+    st.bigdem = (double *)malloc(nbig * sizeof(double));
+    st.bigwater = (double *)malloc(nbig * sizeof(double));
+  }
   if (!st.dem || !st.water || !st.bigdem || !st.bigwater) {
     fprintf(stderr, "WDPMCL: out of memory\n");
     return 1;
   }
+  phase("allocate host rasters");
   asc_read_grid(cfg.dem, st.R, st.C, st.dem);
+  phase("read DEM");
   printf("%s\n", "           ");
   printf("%s\n", "           ");
   for (size_t i = 0; i < ncell; i++)
     if (st.dem[i] > st.missing) st.basincount++;                               /* :643-650 */
 
   setup_module(&cfg, &st);
+  phase("set-up (water file, module)");
 
   /* unit conversions, WDPMCL.c:417-420 / :473-476 / :528-530 */
   const double eltol = cfg.eltol / 1000.0;
@@ -605,6 +677,7 @@ int main(int argc, char **argv) {
           ndev == 1 ? "" : "s, row-block decomposition", devices[0]);
   ABI_TRY(wdpm_group_upload(ctx, st.bigdem, st.bigwater));
   if (cfg.module == WDPM_DRAIN) ABI_TRY(wdpm_group_set_totaldrain(ctx, st.totaldrain0));
+  phase("create contexts + upload");
 
   /* block loop, WDPMCL.c:1049-1377 */
   struct timeval t0;
@@ -636,12 +709,15 @@ int main(int argc, char **argv) {
       scratch_submit(&scratch, st.water);
     }
   }
+  phase("block loop");
   if (write_scratch) scratch_finish(&scratch);
+  phase("wait for checkpoint writer");
 
   double totaldrain = 0;
   ABI_TRY(wdpm_group_download_water(ctx, st.bigwater));
   if (cfg.module == WDPM_DRAIN) ABI_TRY(wdpm_group_get_totaldrain(ctx, &totaldrain));
   wdpm_group_destroy(ctx);
+  phase("download + destroy");
 
   /* final statistics, WDPMCL.c:1379-1467 */
   unpad_water(&st, 1);
@@ -664,6 +740,7 @@ int main(int argc, char **argv) {
     if (st.water[i] > maxdepth) maxdepth = st.water[i];
   maxdepth = maxdepth * 1000;
 
+  phase("final statistics");
   printf("%s\n", "                     ");                                      /* :1832-1857 */
   printf("%30s\n", "WDPM run summary");
   printf("%20s %10.2f %s\n", "Initial volume", st.initial_vol, "m3");
@@ -680,7 +757,9 @@ int main(int argc, char **argv) {
   printf("%20s %10.2f %s\n", "Max water depth", maxdepth, "mm ");
 
   asc_write_grid(cfg.output, &hdr, st.R, st.C, st.water);
+  phase("write output raster");
   printf("%20s %10.2f %s\n", "Run Time", seconds_since(&t0), "s");
-  free(st.dem); free(st.water); free(st.bigdem); free(st.bigwater);
+  free(st.dem); free(st.water);
+  if (pinned) { wdpm_host_free(st.bigdem); wdpm_host_free(st.bigwater); } else { free(st.bigdem); free(st.bigwater); }
   return 0;
 }
