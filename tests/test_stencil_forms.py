@@ -15,6 +15,46 @@ def vmax(a, b):
     return r
 
 
+def vmin(a, b):
+    """v_min_f64 (IEEE minNum, -0 < +0)"""
+    with np.errstate(invalid="ignore"):
+        r = np.where(a <= b, a, b)
+    both_zero = (a == 0) & (b == 0)
+    r = np.where(both_zero, np.where(np.signbit(a) | np.signbit(b), -0.0, 0.0), r)
+    r = np.where(np.isnan(a), b, np.where(np.isnan(b), a, r))
+    return r
+
+
+def reference_drain_step(dc, wc, dn, wn, gate, nvalid):
+    """runoffd()'s non-outlet branch for one neighbour (WDPMCL.c:1977-2000), macros as a<b?a:b / a>b?a:b"""
+    with np.errstate(invalid="ignore", over="ignore"):
+        cwe = dc + wc
+        nwe = dn + wn
+        ht = cwe - nwe
+        go = gate & nvalid & (ht > 0)
+        flow = np.where(dc > nwe, wc / 8.0, ((dc - dn) + (wc - wn)) / 8.0)
+        flow = np.where(flow > 0.0, flow, 0.0)
+        flow = np.where(flow < wc, flow, wc)
+        wc2 = wc - flow
+        wc2 = np.where(wc2 > 0.0, wc2, 0.0)
+        return np.where(go, wc2, wc), np.where(go, wn + flow, wn)
+
+
+def nz_drain_step(dc, wc, dn, wn, gate, nvalid):
+    """wdpm_stencil.h::flow_drain_nz"""
+    with np.errstate(invalid="ignore", over="ignore"):
+        dce = np.where(gate, dc, -np.inf)
+        dnn = np.where(nvalid, dn, np.inf)
+        nwe = dnn + wn
+        ht = (dce + wc) - nwe
+        s = (dce - dnn) + (wc - wn)
+        big = np.where(ht > 0, np.inf, np.where(ht < 0, -np.inf, ht))      # v_ldexp_f64(ht, 2200)
+        x = np.where(dce > nwe, wc, vmin(s, big))
+        f = vmin(x * 0.125, wc)
+        f = vmax(f, np.full_like(x, -0.0))
+        return wc - np.abs(f), wn + f
+
+
 def reference_step(dc, wc, dn, wn, gate, nvalid):
     """runoffs() for one neighbour; gate = centre test (:1099), nvalid = bigdem[n] > missing (:1944)"""
     with np.errstate(invalid="ignore", over="ignore"):
@@ -88,3 +128,21 @@ def test_min_is_a_noop_when_water_moves():
             flow = np.where(dc > en, wc / 8.0, ht / 8.0)
             go = (wc > 0) & (ht > 0)
         assert (flow[go] <= wc[go]).all()
+
+
+def test_nz_drain_form_equals_reference_form():
+    """flow_drain_nz (16 instructions: the sign of ht carried by ldexp, no select on the updates,
+    the outer max dropped) against runoffd()'s conditional form.  The drain sweep only calls it for
+    centres with w_c > 0 (WDPMCL.c:1081); negative neighbour depths from odd input files included."""
+    rng = np.random.default_rng(17)
+    total = 0
+    for _ in range(12):
+        dc, wc, dn, wn, gate, nvalid = operands(rng, 2_000_000)
+        a = reference_drain_step(dc, wc, dn, wn, gate, nvalid)
+        b = nz_drain_step(dc, wc, dn, wn, gate, nvalid)
+        for u, v, name in ((a[0], b[0], "centre"), (a[1], b[1], "neighbour")):
+            bad = u.view(np.uint64) != v.view(np.uint64)
+            assert not bad.any(), (name, int(bad.sum()), dc[bad][:3], wc[bad][:3], dn[bad][:3], wn[bad][:3],
+                                   u[bad][:3], v[bad][:3])
+        total += len(dc)
+    assert total >= 2e7

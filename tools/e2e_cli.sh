@@ -3,7 +3,7 @@
 #   tools/e2e_cli.sh [n]      (needs tools/_build/synth_asc: see tools/synth_asc.c)
 cd $GRAFT_REPO_ROOT; N=${1:-8192}; W=/tmp/e2e_$N; mkdir -p $W
 BIN=$PWD/wdpm_amd/bin/WDPMCL
-/usr/bin/time -f "synth_asc %e s" tools/_build/synth_asc $N $W/dem.asc
+SECONDS=0; tools/_build/synth_asc $N $W/dem.asc; echo "synth_asc ${SECONDS} s"
 ls -la $W/dem.asc | awk '{print "dem.asc bytes", $5}'
 cd $W
 run() { echo "--- $*"; ( "$@" | grep -E "^ +[0-9]+ |Run Time|Final volume" | tail -n 5 ) 2>&1 | grep -v amdgpu.ids; }

@@ -94,8 +94,10 @@ __device__ __forceinline__ void step_drain(const double dc, double &wc, const do
   flow_drain(dc, wc, dn, wn, gate & !hit);                // :1988-2000
 }
 
-/* one 3x3 block of one colour pass: centre (1,1), neighbours in row-major order */
-template <int MODULE, bool SZ_SAFE>
+/* one 3x3 block of one colour pass: centre (1,1), neighbours in row-major order.  OUTLET (drain
+ * only): this block may touch the outlet cell, run runoffd()'s outlet branch too; the caller knows
+ * wave-uniformly that it cannot for all but a handful of the raster's blocks. */
+template <int MODULE, bool SZ_SAFE, bool OUTLET = true>
 __device__ __forceinline__ void block_update(
     double &w00, double &w01, double &w02, double &w10, double &w11, double &w12, double &w20, double &w21,
     double &w22, const double d00, const double d01, const double d02, const double d10, const double d11,
@@ -104,7 +106,26 @@ __device__ __forceinline__ void block_update(
     DrainState &ds) {
   double wc = w11;
   bool gate = (wc > 0.0) & (d11 < WDPM_INF);            // WDPMCL.c:1099
-  if (MODULE == 2) {
+  if (MODULE == 2 && !OUTLET && !SZ_SAFE) {
+    const double dce = gate ? d11 : -WDPM_INF;           // see flow_drain_nz
+    flow_drain_nz(dce, wc, d00, w00);
+    flow_drain_nz(dce, wc, d01, w01);
+    flow_drain_nz(dce, wc, d02, w02);
+    flow_drain_nz(dce, wc, d10, w10);
+    flow_drain_nz(dce, wc, d12, w12);
+    flow_drain_nz(dce, wc, d20, w20);
+    flow_drain_nz(dce, wc, d21, w21);
+    flow_drain_nz(dce, wc, d22, w22);
+  } else if (MODULE == 2 && !OUTLET) {
+    flow_drain(d11, wc, d00, w00, gate);
+    flow_drain(d11, wc, d01, w01, gate);
+    flow_drain(d11, wc, d02, w02, gate);
+    flow_drain(d11, wc, d10, w10, gate);
+    flow_drain(d11, wc, d12, w12, gate);
+    flow_drain(d11, wc, d20, w20, gate);
+    flow_drain(d11, wc, d21, w21, gate);
+    flow_drain(d11, wc, d22, w22, gate);
+  } else if (MODULE == 2) {
     gate = gate & !(rd1 & cd1);                          // :1082 the outlet is never a centre
     ds.hit = false;
     step_drain(d11, wc, d00, w00, gate, rd0 & cd0, ds);
@@ -143,35 +164,51 @@ __device__ __forceinline__ void block_update(
 }
 
 /* the three column alignments oj = 1,2,3 of one row alignment, on window slots S0..S0+2 */
-template <int MODULE, bool SZ_SAFE, int S0>
-__device__ __forceinline__ void stage(double (&W)[7][3], const double (&D)[7][3], const int row_s0,
-                                      const int drain_row, const bool (&cdr)[5], DrainState &ds) {
-  const bool rd0 = MODULE == 2 && row_s0 == drain_row;
-  const bool rd1 = MODULE == 2 && row_s0 + 1 == drain_row;
-  const bool rd2 = MODULE == 2 && row_s0 + 2 == drain_row;
+template <int MODULE, bool SZ_SAFE, int S0, bool OUTLET>
+__device__ __forceinline__ void stage_impl(double (&W)[7][3], const double (&D)[7][3], const int row_s0,
+                                           const int drain_row, const bool (&cdr)[5], DrainState &ds) {
+  const bool rd0 = MODULE == 2 && OUTLET && row_s0 == drain_row;
+  const bool rd1 = MODULE == 2 && OUTLET && row_s0 + 1 == drain_row;
+  const bool rd2 = MODULE == 2 && OUTLET && row_s0 + 2 == drain_row;
   constexpr int a = S0, b = S0 + 1, c = S0 + 2;
   // oj = 1: own columns 0,1,2
-  block_update<MODULE, SZ_SAFE>(W[a][0], W[a][1], W[a][2], W[b][0], W[b][1], W[b][2], W[c][0], W[c][1], W[c][2],
+  block_update<MODULE, SZ_SAFE, OUTLET>(W[a][0], W[a][1], W[a][2], W[b][0], W[b][1], W[b][2], W[c][0], W[c][1], W[c][2],
                        D[a][0], D[a][1], D[a][2], D[b][0], D[b][1], D[b][2], D[c][0], D[c][1], D[c][2],
                        rd0, rd1, rd2, cdr[0], cdr[1], cdr[2], ds);
   // oj = 2: own columns 1,2 + column 0 of the next lane
   double wa0 = lane_next(W[a][0]), wb0 = lane_next(W[b][0]), wc0 = lane_next(W[c][0]);
   const double da0 = lane_next(D[a][0]), db0 = lane_next(D[b][0]),
                dc0 = lane_next(D[c][0]);
-  block_update<MODULE, SZ_SAFE>(W[a][1], W[a][2], wa0, W[b][1], W[b][2], wb0, W[c][1], W[c][2], wc0,
+  block_update<MODULE, SZ_SAFE, OUTLET>(W[a][1], W[a][2], wa0, W[b][1], W[b][2], wb0, W[c][1], W[c][2], wc0,
                        D[a][1], D[a][2], da0, D[b][1], D[b][2], db0, D[c][1], D[c][2], dc0,
                        rd0, rd1, rd2, cdr[1], cdr[2], cdr[3], ds);
   // oj = 3: own column 2 + columns 0,1 of the next lane
   double wa1 = lane_next(W[a][1]), wb1 = lane_next(W[b][1]), wc1 = lane_next(W[c][1]);
   const double da1 = lane_next(D[a][1]), db1 = lane_next(D[b][1]),
                dc1 = lane_next(D[c][1]);
-  block_update<MODULE, SZ_SAFE>(W[a][2], wa0, wa1, W[b][2], wb0, wb1, W[c][2], wc0, wc1,
+  block_update<MODULE, SZ_SAFE, OUTLET>(W[a][2], wa0, wa1, W[b][2], wb0, wb1, W[c][2], wc0, wc1,
                        D[a][2], da0, da1, D[b][2], db0, db1, D[c][2], dc0, dc1,
                        rd0, rd1, rd2, cdr[2], cdr[3], cdr[4], ds);
   // hand the borrowed columns back to lane+1; lane 0 keeps its own (nothing to its left)
   W[a][0] = lane_prev(wa0, W[a][0]);  W[a][1] = lane_prev(wa1, W[a][1]);
   W[b][0] = lane_prev(wb0, W[b][0]);  W[b][1] = lane_prev(wb1, W[b][1]);
   W[c][0] = lane_prev(wc0, W[c][0]);  W[c][1] = lane_prev(wc1, W[c][1]);
+}
+
+/* Drain: the outlet branch of runoffd() costs ten more instructions per neighbour step, and exactly
+ * one cell of the raster needs it.  Whether any of the three rows of this stage is the outlet's row
+ * is wave-uniform (`near_outlet` is computed on the scalar unit), so all other stages run the plain
+ * neighbour step. */
+template <int MODULE, bool SZ_SAFE, int S0>
+__device__ __forceinline__ void stage(double (&W)[7][3], const double (&D)[7][3], const int row_s0,
+                                      const int drain_row, const bool (&cdr)[5], DrainState &ds) {
+  if (MODULE == 2) {
+    const bool near_outlet = row_s0 <= drain_row && drain_row <= row_s0 + 2;     // wave-uniform
+    if (near_outlet) stage_impl<MODULE, SZ_SAFE, S0, true>(W, D, row_s0, drain_row, cdr, ds);
+    else stage_impl<MODULE, SZ_SAFE, S0, false>(W, D, row_s0, drain_row, cdr, ds);
+  } else {
+    stage_impl<MODULE, SZ_SAFE, S0, false>(W, D, row_s0, drain_row, cdr, ds);
+  }
 }
 
 #ifndef WDPM_FUSED_MIN_WAVES
@@ -969,8 +1006,9 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
   if (A0 < 0 || A0 % 3 != 0 || out_last > g.rows - 1 || out_last < A0) return hipErrorInvalidValue;
   int nstrips = 1;
   if (g.ncp > kStripIn - kHaloR) nstrips = (g.ncp - (kStripIn - kHaloR) + kStripOut - 1) / kStripOut + 1;
-  const bool fast = module != 2 && !signed_zero_safe;
-  int slots = module == 2 ? resident_waves<2, true>() : fast ? resident_waves<0, false>() : resident_waves<0, true>();
+  const bool fast = !signed_zero_safe;
+  int slots = module == 2 ? (fast ? resident_waves<2, false>() : resident_waves<2, true>())
+                          : fast ? resident_waves<0, false>() : resident_waves<0, true>();
   {
     // The kernel is HBM-bound with ONE wave per SIMD already; a second wave per SIMD only adds
     // concurrent DRAM row streams and, on rasters too small to fill the chip, makes the dispatcher
@@ -988,7 +1026,9 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
   if (nchunks < 1) nchunks = 1;
   const int nitems = nstrips * nchunks;
   const dim3 grid(((nitems + 3) / 4 + 7) / 8 * 8), block(256);   // multiple of 8: see the XCD remap
-  if (module == 2)
+  if (module == 2 && fast)
+    hipLaunchKernelGGL((fused_iteration_kernel<2, false>), grid, block, 0, s, w_in, w_out, dem, g, nstrips, nitems, H, A0, out_last, totaldrain);
+  else if (module == 2)
     hipLaunchKernelGGL((fused_iteration_kernel<2, true>), grid, block, 0, s, w_in, w_out, dem, g, nstrips, nitems, H, A0, out_last, totaldrain);
   else if (fast)
     hipLaunchKernelGGL((fused_iteration_kernel<0, false>), grid, block, 0, s, w_in, w_out, dem, g, nstrips, nitems, H, A0, out_last, totaldrain);
