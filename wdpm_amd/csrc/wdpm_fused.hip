@@ -1015,8 +1015,15 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
     // double up waves on some SIMDs while others idle.  Filling half of the resident slots measured
     // +4 % at 16384^2, +13 % at 6000^2, x1.9 at 1500^2, x2.3 at 1024^2 (-4 % at 4096^2).
     // WDPM_FILL_PERCENT overrides (tuning only).
-    static int pct = -1;
-    if (pct < 0) { const char *e = getenv("WDPM_FILL_PERCENT"); pct = e ? atoi(e) : 50; }
+    // The drain variant is different: 16 instructions per neighbour step on one dependent chain per
+    // lane leave it latency-bound (59 % VALU issue at one wave per SIMD), and a second wave per SIMD
+    // fills the bubbles: +21 % at 8192^2, +30 % at 16384^2 - as long as the chunks stay tall enough
+    // (>= 48 rows) for the 6-row warm-up of each not to eat the gain.
+    static int env_pct = -1;
+    if (env_pct < 0) { const char *e = getenv("WDPM_FILL_PERCENT"); env_pct = e ? atoi(e) : 0; }
+    int pct = 50;
+    if (module == 2 && (long long)(out_last - A0 + 1) * nstrips >= 48LL * slots) pct = 100;
+    if (env_pct > 0) pct = env_pct;
     if (pct > 0 && pct < 100) slots = slots * pct / 100;
   }
   const int wrows = out_last - A0 + 1;                       // rows of this launch's window
