@@ -34,7 +34,7 @@ for ln, text in enumerate(lines, 1):
     for m in re.finditer(r"\b([va])(\d+)\b", t):
         regs.add((1000 if m.group(1) == "a" else 0) + int(m.group(2)))
     if in_asm and t.startswith("global_load"):
-        m = re.match(r"global_load_dwordx2 ([va])\[(\d+):(\d+)\]", t)
+        m = re.match(r"global_load_dwordx[24] ([va])\[(\d+):(\d+)\]", t)
         base = 1000 if m.group(1) == "a" else 0
         dst = set(range(base + int(m.group(2)), base + int(m.group(3)) + 1))
         for r in dst:
