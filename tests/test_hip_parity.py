@@ -186,14 +186,22 @@ def test_rowblock_solver_single_rank_on_gpu(hip, oracle):
     s.close()
 
 
-def test_negative_zero_depths_keep_their_sign(hip, oracle):
+def module_kw(module, bd, nrows, ncols, miss):
+    kw = dict(module=module, nrows=nrows, ncols=ncols, missingvalue=miss)
+    if module == "drain":
+        kw["drainrow"], kw["draincol"] = find_drain(bd)
+    return kw
+
+
+@pytest.mark.parametrize("module", ["add", "drain"])
+def test_negative_zero_depths_keep_their_sign(hip, oracle, module):
     """a -0.0 depth in the input makes the library pick the sign-preserving stencil variant by
     itself; results equal the oracle bit for bit, sign of zero included"""
     dem, water, miss = random_case(31, 60, 220, dry_frac=0.5)
     water[(water == 0) & (np.arange(water.size).reshape(water.shape) % 3 == 0)] = -0.0
     bd, bw = pad(dem, water, miss)
     assert np.signbit(bw[bw == 0]).any()
-    kw = dict(module="add", nrows=60, ncols=220, missingvalue=miss)
+    kw = module_kw(module, bd, 60, 220, miss)
     with hip.context(**kw) as g, oracle.context(**kw) as o:
         g.upload(bd, bw)
         o.upload(bd, bw)
@@ -215,14 +223,16 @@ def test_negative_zero_depths_keep_their_sign(hip, oracle):
         assert n_bit_diff(g.download_water(), o.download_water()) == 0
 
 
-def test_negative_and_nan_inputs_are_handled_like_the_reference(hip, oracle):
+@pytest.mark.parametrize("module", ["add", "drain"])
+def test_negative_and_nan_inputs_are_handled_like_the_reference(hip, oracle, module):
     """odd water files: negative depths and NaN cells never give water and are carried through"""
     dem, water, miss = random_case(32, 40, 200)
     water[3, 5] = -0.25
     water[10, 100] = np.nan
     water[20:22, 50:60] = -1e-9
+    water[30, 20:40] = -3.0          # deep negative cells next to wet ones: the clamp to [0, w_c] matters
     bd, bw = pad(dem, water, miss)
-    kw = dict(module="add", nrows=40, ncols=200, missingvalue=miss)
+    kw = module_kw(module, bd, 40, 200, miss)
     with hip.context(**kw) as g, oracle.context(**kw) as o:
         g.upload(bd, bw)
         o.upload(bd, bw)

@@ -45,14 +45,15 @@ def nz_drain_step(dc, wc, dn, wn, gate, nvalid):
     with np.errstate(invalid="ignore", over="ignore"):
         dce = np.where(gate, dc, -np.inf)
         dnn = np.where(nvalid, dn, np.inf)
+        wcl = np.where(gate, wc, 0.0)           # the block runs on a local centre depth (wdpm_fused.hip)
         nwe = dnn + wn
-        ht = (dce + wc) - nwe
-        s = (dce - dnn) + (wc - wn)
+        ht = (dce + wcl) - nwe
+        s = (dce - dnn) + (wcl - wn)
         big = np.where(ht > 0, np.inf, np.where(ht < 0, -np.inf, ht))      # v_ldexp_f64(ht, 2200)
-        x = np.where(dce > nwe, wc, vmin(s, big))
-        f = vmin(x * 0.125, wc)
-        f = vmax(f, np.full_like(x, -0.0))
-        return wc - np.abs(f), wn + f
+        x = np.where(dce > nwe, wcl, vmin(s, big))
+        f = vmax(x * 0.125, np.full_like(x, -0.0))
+        f = vmin(f, wcl)
+        return np.where(gate, wcl - np.abs(f), wc), wn + f
 
 
 def reference_step(dc, wc, dn, wn, gate, nvalid):
@@ -97,6 +98,8 @@ def operands(rng, n):
                    10.0 ** rng.uniform(-18, 3, n))
     wn = np.where(rng.random(n) < 0.02, -np.abs(wn) - 1e-300, wn)   # negative depths from odd input files
     wn = np.where((wn == 0) & np.signbit(wn), 0.0, wn)               # the documented precondition: no -0.0
+    wn = np.where(rng.random(n) < 0.005, np.nan, wn)                 # NaN cells of odd input files
+    wc = np.where(rng.random(n) < 0.005, np.nan, wc)
     gate = (wc > 0.0) & (rng.random(n) < 0.95)
     nvalid = rng.random(n) < 0.93
     return dc, wc, dn, wn, gate, nvalid

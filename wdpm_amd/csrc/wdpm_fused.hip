@@ -108,6 +108,7 @@ __device__ __forceinline__ void block_update(
   bool gate = (wc > 0.0) & (d11 < WDPM_INF);            // WDPMCL.c:1099
   if (MODULE == 2 && !OUTLET && !SZ_SAFE) {
     const double dce = gate ? d11 : -WDPM_INF;           // see flow_drain_nz
+    wc = gate ? wc : 0.0;                                // its clamp needs a centre depth >= +0
     flow_drain_nz(dce, wc, d00, w00);
     flow_drain_nz(dce, wc, d01, w01);
     flow_drain_nz(dce, wc, d02, w02);
@@ -116,6 +117,7 @@ __device__ __forceinline__ void block_update(
     flow_drain_nz(dce, wc, d20, w20);
     flow_drain_nz(dce, wc, d21, w21);
     flow_drain_nz(dce, wc, d22, w22);
+    wc = gate ? wc : w11;
   } else if (MODULE == 2 && !OUTLET) {
     flow_drain(d11, wc, d00, w00, gate);
     flow_drain(d11, wc, d01, w01, gate);

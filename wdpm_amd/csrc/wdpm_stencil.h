@@ -113,15 +113,17 @@ __device__ __forceinline__ void flow_drain(const double dem_c, double &w_c, cons
  *   reference (:1988-2000)                          here
  *   if (ht > 0) {                                   big = ldexp(ht, 2200): +inf / 0 / -inf by sign
  *     flow = dem_c > nwe ? w_c/8 : s/8              x = dem_c > nwe ? w_c : min(s, big);  x/8
- *     flow = min(max(flow, 0.0), w_c)               f = max(min(x/8, w_c), -0.0)
+ *     flow = min(max(flow, 0.0), w_c)               f = min(max(x/8, -0.0), w_c)
  *     w_c = max(w_c - flow, 0.0)                    w_c - |f|      (the max is a no-op: f <= w_c)
  *     w_n = w_n + flow }                            w_n + f
  *   with s = (dem_c - dem_n) + (w_c - w_n).
  *
- * ht > 0: big = +inf, so x is the reference's operand; clamping to [0, w_c] in the other order gives
- *   the same value for w_c >= 0 (the max comes last so that a cell with a negative depth from an odd
- *   input file, never a centre, still sees a zero flow); max(.., -0.0) differs from max(.., 0.0) only
+ * `w_c` must be >= +0: the caller runs a block whose centre may not give water (dry, negative or NaN
+ * depth from an odd input file, NODATA) on a local centre depth of 0.0 and keeps the cell's value.
+ * ht > 0: big = +inf, so x is the reference's operand; max(.., -0.0) differs from max(.., 0.0) only
  *   by the sign of a zero flow, and w - |+-0| == w, w_n + (+-0) == w_n (w_n is not -0.0).
+ * NaN anywhere (an odd input file): x is NaN, v_max returns its other operand, f = -0.0: no transfer,
+ *   as with the reference's `ht > 0` test.
  * ht <= 0, -inf: dem_c > nwe is impossible [it implies ht > 0 for w_c >= 0, see flow_add_nz (a)], so
  *   x = min(s, big) <= 0 whatever the sign of s (s and ht are rounded differently and may disagree
  *   about the sign of a difference near zero: the reference tests ht, so must we), f = +-0, and
@@ -133,8 +135,8 @@ __device__ __forceinline__ void flow_drain_nz(const double dem_c, double &w_c, c
   const double s = (dem_c - dem_n) + (w_c - w_n);               // :1995-1996
   const double big = __builtin_ldexp(ht, 2200);                 // :1989 the sign of ht as +inf / 0 / -inf
   const double x = (dem_c > nwe) ? w_c : vmin_f64(s, big);      // :1990-1996
-  double f = vmin_f64(x * 0.125, w_c);                          // :1998 min(.., w_c)
-  f = vmax_f64(f, -0.0);                                        // :1998 max(flow, 0.0), see above
+  double f = vmax_f64(x * 0.125, -0.0);                         // :1998 max(flow, 0.0); NaN -> -0.0
+  f = vmin_f64(f, w_c);                                         // :1998 min(.., w_c)
   w_c = w_c - __builtin_fabs(f);                                // :1999
   w_n = w_n + f;                                                // :2000
 }
