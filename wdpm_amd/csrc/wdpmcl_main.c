@@ -627,9 +627,12 @@ int main(int argc, char **argv) {
   const size_t ncell = (size_t)st.R * st.C, nbig = (size_t)(st.R + 2) * (st.C + 2);
   st.dem = (double *)calloc(ncell, sizeof(double));
   st.water = (double *)calloc(ncell, sizeof(double));
-  /* the two rasters that travel to and from the device: staging memory from the library
-   * (page-locked on the HIP back-end); WDPM_PINNED=0 keeps them in ordinary memory */
-  const int pinned = !(getenv("WDPM_PINNED") && atoi(getenv("WDPM_PINNED")) == 0);
+  /* the two rasters that travel to and from the device come from the library (page-locked on the
+   * HIP back-end) when the run writes checkpoints, i.e. downloads the raster after every block:
+   * page-locking costs ~0.3 s per GiB once and saves ~40 ms per GiB on every transfer (measured at
+   * 8192^2), so a run with three transfers in all is better off with ordinary memory.
+   * WDPM_PINNED=0/1 overrides. */
+  const int pinned = getenv("WDPM_PINNED") ? atoi(getenv("WDPM_PINNED")) != 0 : !is_null_name(cfg.scratch);
   if (pinned) {
     void *a = NULL, *b = NULL;
     ABI_TRY(wdpm_host_alloc(nbig * sizeof(double), &a));
