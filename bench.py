@@ -82,8 +82,8 @@ def cpu_baseline(n=4096, iters=32):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=1000)   # one block of the reference loop
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--size", type=int, default=16384)
     ap.add_argument("--exchange-every", type=int, default=int(os.environ.get("WDPM_EXCHANGE_EVERY", "4")))
     ap.add_argument("--kernel", choices=["auto", "pass", "fused", "fused2", "fused2w"], default="auto")
@@ -215,7 +215,7 @@ def main():
                          "kernel_ms_per_iteration": iter_ms, "launches": launches,
                          "job_frac": value * ALGO_BYTES_PER_CELL_UPDATE / 1e9 / (HBM_PEAK_GBS * world)},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     solver.close()

@@ -1,12 +1,12 @@
 #!/bin/bash
 # Round profile: kernel trace + stats, then the two HBM-counter passes, each its own rocprofv3 run.
-# usage (on the GPU box): bash tools/profile.sh <name>     -> gpurun_out/<name>/
-R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$1
+# usage (on the GPU box): bash tools/profile.sh <name> [extra bench.py arguments]    -> gpurun_out/<name>/
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$1; shift; X="$*"
 mkdir -p $OUT; cd /tmp && export TMPDIR=/tmp
-timeout -k 10 250 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 100 --warmup 5 --no-cpu-baseline > $OUT/trace.log 2>&1 &&
-timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/fetch.log 2>&1 &&
-timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/write.log 2>&1 &&
-timeout -k 10 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/sq -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/sq.log 2>&1
+timeout -k 10 250 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 100 --warmup 5 --no-cpu-baseline $X > $OUT/trace.log 2>&1 &&
+timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline $X > $OUT/fetch.log 2>&1 &&
+timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline $X > $OUT/write.log 2>&1 &&
+timeout -k 10 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/sq -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline $X > $OUT/sq.log 2>&1
 cd $R
 grep -h '"metric"' $OUT/trace.log | cut -c1-400
 cat $OUT/trace/*/*_kernel_stats.csv
