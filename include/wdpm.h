@@ -169,8 +169,14 @@ int  wdpm_group_drain_stats(wdpm_group *grp, double *diffdrain, double *final_su
  *   (it then runs the kernel variant that keeps the reference's conditional updates); otherwise the
  *   faster variant, which is bit-identical whenever no -0.0 is present (none can be created), runs.
  *   A multi-GPU driver whose transport writes halo rows straight into device memory must OR the
- *   flag over all ranks and set it (wdpm_amd/rowblock.py does). */
-enum { WDPM_OPT_SIGNED_ZERO_SAFE = 1 };
+ *   flag over all ranks and set it (wdpm_amd/rowblock.py does).
+ * WDPM_OPT_DEM32 (get/set): 1 = the iteration kernel streams the static DEM as 32-bit codes
+ *   (4 bytes per cell-update of HBM traffic instead of 8).  Switched on by wdpm_upload when the device
+ *   has verified, cell by cell and bit for bit, that the DEM is k / 10^e with 32-bit k (DEMs read
+ *   from decimal text are); results are identical either way.  Setting 0 forces the fp64 DEM,
+ *   setting 1 is honoured only for a DEM that passed the check.  WDPM_DEM32=0 in the environment
+ *   disables the encoding altogether.  The CPU restatement reports 0. */
+enum { WDPM_OPT_SIGNED_ZERO_SAFE = 1, WDPM_OPT_DEM32 = 2 };
 int wdpm_get_option(wdpm_ctx *ctx, int32_t key, int64_t *value);
 int wdpm_set_option(wdpm_ctx *ctx, int32_t key, int64_t value);
 

@@ -38,8 +38,11 @@ def test_golden_stencil_vectors(hip, stencil_cases, kernel, chunk):
     assert check_stencil_cases(KernelLib(hip, kernel=kernel, chunk_rows=chunk), z, index) > 100
 
 
-def _compare_with_oracle(hip, oracle, module, R, C, seed, iters, kernel, chunk=0, thres=None, **case_kw):
+def _compare_with_oracle(hip, oracle, module, R, C, seed, iters, kernel, chunk=0, thres=None, dem32=None,
+                         dem_digits=4, **case_kw):
     dem, water, miss = random_case(seed, R, C, **case_kw)
+    if dem_digits is None:        # elevations that are not decimal fractions: the fp64 DEM must stay in charge
+        dem = np.where(dem > miss, dem * (1.0 + 2.0 ** -30), dem)
     bd, bw = pad(dem, water, miss)
     kw = dict(module=module, nrows=R, ncols=C, missingvalue=miss)
     td0 = 0.0
@@ -51,6 +54,12 @@ def _compare_with_oracle(hip, oracle, module, R, C, seed, iters, kernel, chunk=0
         for c in (g, o):
             c.upload(bd, bw)
             c.totaldrain = td0
+        if dem32 is not None:
+            # random_case rounds elevations to 4 decimals: the device finds them encodable by itself
+            encodable = dem_digits is not None and bool((dem > miss).any())
+            assert g.get_option(wdpm_amd.OPT_DEM32) == int(encodable)
+            g.set_option(wdpm_amd.OPT_DEM32, dem32)
+            assert g.get_option(wdpm_amd.OPT_DEM32) == int(bool(dem32) and encodable)
         for n in iters:
             if thres is not None:
                 mg, mo = g.run_block(n, thres), o.run_block(n, thres)
@@ -73,6 +82,52 @@ def _compare_with_oracle(hip, oracle, module, R, C, seed, iters, kernel, chunk=0
 @pytest.mark.parametrize("R,C,chunk", [(38, 398, 12), (100, 700, 0), (301, 170, 48), (64, 1100, 30), (5, 175, 3)])
 def test_random_rasters_match_oracle(hip, oracle, module, kernel, R, C, chunk):
     _compare_with_oracle(hip, oracle, module, R, C, seed=R * 1000 + C, iters=(1, 2, 25), kernel=kernel, chunk=chunk)
+
+
+@pytest.mark.parametrize("dem32", [0, 1])
+@pytest.mark.parametrize("module", ["add", "subtract"])
+@pytest.mark.parametrize("R,C,chunk", [(38, 398, 12), (100, 700, 0), (301, 170, 48), (64, 1100, 30), (5, 175, 3), (1, 1, 0)])
+def test_dem_codes_on_and_off(hip, oracle, module, R, C, chunk, dem32):
+    """the one-iteration kernel with the DEM streamed as verified 32-bit codes (WDPM_OPT_DEM32) and with
+    the fp64 DEM: same bits as the oracle either way, edge strips and ragged sizes included"""
+    _compare_with_oracle(hip, oracle, module, R, C, seed=R * 1000 + C + 1, iters=(1, 2, 25),
+                         kernel=wdpm_amd.KERNEL_FUSED, chunk=chunk, dem32=dem32)
+
+
+def test_dem_codes_are_refused_for_non_decimal_elevations(hip, oracle):
+    _compare_with_oracle(hip, oracle, "add", 60, 400, seed=77, iters=(5,), kernel=wdpm_amd.KERNEL_FUSED, dem32=1,
+                         dem_digits=None)
+
+
+@pytest.mark.parametrize("name", ["six_digits_high", "needs_offset", "relief_too_large", "negative", "neg_zero",
+                                  "mixed_digits", "integers", "huge"])
+def test_dem_code_edge_cases(hip, oracle, name):
+    """which DEMs the device accepts as k / 10^e with 32-bit k - and that results never depend on it"""
+    rng = np.random.default_rng(5)
+    R, C, miss = 40, 230, -99999.0
+    base = rng.normal(0, 3, (R, C))
+    dem, want = {
+        "six_digits_high": (np.round(1500.0 + base, 6), 1),                      # k ~ 1.5e9: fits without the offset too
+        "needs_offset": (np.round(3000.0 + base, 6), 1),            # k ~ 3e9 > 2^31: only k - k0 fits
+        "relief_too_large": (np.where(rng.random((R, C)) < 0.5, 1e-6, 5000.000001), 0),
+        "negative": (np.round(-12.0 + base, 3), 1),
+        "neg_zero": (np.where(rng.random((R, C)) < 0.01, -0.0, np.round(3.0 + base, 2)), 0),
+        "mixed_digits": (np.where(rng.random((R, C)) < 0.5, np.round(400 + base, 1), np.round(400 + base, 5)), 1),
+        "integers": (np.round(700.0 + base, 0), 1),
+        "huge": (np.where(rng.random((R, C)) < 0.02, 1e300, np.round(10 + base, 2)), 0),
+    }[name]
+    dem = dem.copy()
+    dem[rng.random((R, C)) < 0.04] = miss
+    water = np.where(dem > miss, 0.2 * rng.random((R, C)), 0.0)
+    bd, bw = pad(dem, water, miss)
+    kw = dict(module="add", nrows=R, ncols=C, missingvalue=miss)
+    with hip.context(**kw) as g, oracle.context(**kw) as o:
+        g.upload(bd, bw)
+        o.upload(bd, bw)
+        assert g.get_option(wdpm_amd.OPT_DEM32) == want
+        g.iterate(12)
+        o.iterate(12)
+        assert n_bit_diff(g.download_water(), o.download_water()) == 0
 
 
 @pytest.mark.parametrize("module", ["add", "subtract", "drain"])

@@ -34,9 +34,10 @@ for ln, text in enumerate(lines, 1):
     for m in re.finditer(r"\b([va])(\d+)\b", t):
         regs.add((1000 if m.group(1) == "a" else 0) + int(m.group(2)))
     if in_asm and t.startswith("global_load"):
-        m = re.match(r"global_load_dwordx[24] ([va])\[(\d+):(\d+)\]", t)
+        m = re.match(r"global_load_dword(?:x[234])? ([va])(?:\[(\d+):(\d+)\]|(\d+))", t)
         base = 1000 if m.group(1) == "a" else 0
-        dst = set(range(base + int(m.group(2)), base + int(m.group(3)) + 1))
+        lo, hi = (int(m.group(2)), int(m.group(3))) if m.group(2) else (int(m.group(4)), int(m.group(4)))
+        dst = set(range(base + lo, base + hi + 1))
         for r in dst:
             if r in inflight:
                 print(f"line {ln}: load overwrites in-flight v{r} (loaded at line {inflight[r]})"); bad += 1

@@ -1,3 +1,3 @@
 """wdpm_amd — MI355X-native WDPM water-redistribution path."""
-from .capi import (ADD, SUBTRACT, DRAIN, MODULES, KERNEL_AUTO, KERNEL_PASS, KERNEL_FUSED, KERNEL_FUSED2, KERNEL_FUSED2W, OPT_SIGNED_ZERO_SAFE,  # noqa: F401
+from .capi import (ADD, SUBTRACT, DRAIN, MODULES, KERNEL_AUTO, KERNEL_PASS, KERNEL_FUSED, KERNEL_FUSED2, KERNEL_FUSED2W, OPT_SIGNED_ZERO_SAFE, OPT_DEM32,  # noqa: F401
                    Context, Lib, WdpmError, load, load_hip, HIP_LIB_PATH)

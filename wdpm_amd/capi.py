@@ -17,6 +17,7 @@ ADD, SUBTRACT, DRAIN = 0, 1, 2
 MODULES = {"add": ADD, "subtract": SUBTRACT, "drain": DRAIN}
 KERNEL_AUTO, KERNEL_PASS, KERNEL_FUSED, KERNEL_FUSED2, KERNEL_FUSED2W = 0, 1, 2, 3, 4
 OPT_SIGNED_ZERO_SAFE = 1
+OPT_DEM32 = 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # WDPM_HIP_LIB lets a tuning run point at an alternative build of the same HIP library

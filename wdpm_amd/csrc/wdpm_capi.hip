@@ -55,6 +55,9 @@ struct wdpm_ctx {
   std::vector<unsigned char> h_valid; /* bigdem > missingvalue per cell, kept only for wdpm_drain_stats */
   int kernel;                   /* resolved WDPM_KERNEL_* */
   bool signed_zero_safe;        /* a -0.0 depth was uploaded (or the caller asked): exact-zero stencil variant */
+  int *d_dem32;                 /* the DEM as verified-lossless 32-bit codes (wdpm_kernels.h::DemCode) */
+  DemCode code;                 /* code.q == d_dem32 while the uploaded DEM is encodable and the option is on */
+  bool dem32_encodable;
   /* wdpm_iterate_overlapped: side stream for the interior launch and the event that joins it */
   hipStream_t side;
   hipEvent_t ev_fork, ev_join;
@@ -127,6 +130,7 @@ int wdpm_create(wdpm_ctx **out, const wdpm_params *p) {
   x->ms = 0.0;
   x->d_dem = x->d_w[0] = x->d_w[1] = x->d_old = nullptr;
   x->d_scal = nullptr; x->d_bits = nullptr; x->h_pin = nullptr;
+  x->d_dem32 = nullptr; x->code = DemCode{nullptr, 0.0, 1.0, 1.0}; x->dem32_encodable = false;
   x->h_sum[0] = x->h_sum[1] = nullptr; x->ev_sum[0] = x->ev_sum[1] = nullptr;
   x->own_stream = true;
   x->side = nullptr; x->ev_fork = nullptr; x->ev_join = nullptr; x->pending_join = false;
@@ -140,6 +144,7 @@ int wdpm_create(wdpm_ctx **out, const wdpm_params *p) {
   if (e == hipSuccess) e = hipMalloc(&x->d_w[0], bytes + 64 * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&x->d_w[1], bytes + 64 * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&x->d_old, bytes);
+  if (e == hipSuccess) e = hipMalloc(&x->d_dem32, x->cells * sizeof(int) + 64);
   if (e == hipSuccess) e = hipMalloc(&x->d_scal, 2 * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&x->d_bits, sizeof(unsigned long long));
   if (e == hipSuccess) e = hipHostMalloc(&x->h_pin, 4 * sizeof(double));
@@ -165,7 +170,7 @@ void wdpm_destroy(wdpm_ctx *x) {
   for (auto &ep : x->pending) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
   for (auto &ep : x->pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
   (void)hipFree(x->d_dem); (void)hipFree(x->d_w[0]); (void)hipFree(x->d_w[1]); (void)hipFree(x->d_old);
-  (void)hipFree(x->d_scal); (void)hipFree(x->d_bits);
+  (void)hipFree(x->d_scal); (void)hipFree(x->d_bits); (void)hipFree(x->d_dem32);
   if (x->h_pin) (void)hipHostFree(x->h_pin);
   for (int i = 0; i < 2; i++) {
     if (x->h_sum[i]) (void)hipHostFree(x->h_sum[i]);
@@ -203,6 +208,39 @@ static int note_negzero(wdpm_ctx *x, int row, int nrows) {
   return 0;
 }
 
+/* Try to express the DEM just uploaded as 32-bit codes k with dem == (k + k0) / 10^e bit for bit
+ * (e = 0..6, the smallest that works; real DEMs are decimal text).  The device checks every cell
+ * with the decoder the iteration kernel uses; any miss leaves the fp64 DEM in charge. */
+static int encode_dem(wdpm_ctx *x) {
+  x->dem32_encodable = false;
+  x->code.q = nullptr;
+  const char *env = getenv("WDPM_DEM32");
+  if (env && atoi(env) == 0) return 0;
+  HIP_TRY(wdpm_launch_dem_min(x->d_dem, x->cells, x->d_bits, x->stream));
+  HIP_TRY(hipMemcpyAsync(x->h_pin, x->d_bits, sizeof(double), hipMemcpyDeviceToHost, x->stream));
+  HIP_TRY(hipStreamSynchronize(x->stream));
+  unsigned long long key;
+  memcpy(&key, x->h_pin, sizeof key);
+  if (key == ~0ull) return 0;                                  /* no valid cell at all */
+  const double vmin = wdpm_dem_key_to_double(key);
+  static const double p10[7] = {1.0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6};
+  for (int e = 0; e <= 6; e++) {
+    const double D = p10[e], rD = 1.0 / D, k0 = rint(vmin * D);
+    if (!(fabs(k0) < 4.0e15)) break;                           /* k = q + k0 must stay an exact integer */
+    HIP_TRY(wdpm_launch_dem_encode(x->d_dem, x->cells, k0, D, rD, x->d_dem32, x->d_bits, x->stream));
+    HIP_TRY(hipMemcpyAsync(x->h_pin, x->d_bits, sizeof(double), hipMemcpyDeviceToHost, x->stream));
+    HIP_TRY(hipStreamSynchronize(x->stream));
+    unsigned long long bad;
+    memcpy(&bad, x->h_pin, sizeof bad);
+    if (!bad) {
+      x->dem32_encodable = true;
+      x->code = DemCode{x->d_dem32, k0, D, rD};
+      break;
+    }
+  }
+  return 0;
+}
+
 int wdpm_upload(wdpm_ctx *x, const double *bigdem, const double *bigwater) {
   if (!bigdem || !bigwater) return fail("wdpm_upload: null array");
   if (bind(x)) return 1;
@@ -212,6 +250,7 @@ int wdpm_upload(wdpm_ctx *x, const double *bigdem, const double *bigwater) {
   HIP_TRY(wdpm_launch_mark_nodata(x->d_dem, x->cells, x->g.miss, x->stream));
   x->signed_zero_safe = false;
   if (note_negzero(x, 0, x->g.rows)) return 1;
+  if (encode_dem(x)) return 1;
   if (x->p.module == WDPM_DRAIN) {
     x->h_valid.resize(x->cells);
     for (size_t i = 0; i < x->cells; i++) x->h_valid[i] = bigdem[i] > x->g.miss;
@@ -274,14 +313,22 @@ int wdpm_copy_rows(wdpm_ctx *dst, int32_t dst_row, wdpm_ctx *src, int32_t src_ro
 }
 
 int wdpm_get_option(wdpm_ctx *x, int32_t key, int64_t *value) {
-  if (key != WDPM_OPT_SIGNED_ZERO_SAFE || !value) return fail("wdpm_get_option: unknown option %d", key);
-  *value = x->signed_zero_safe ? 1 : 0;
+  if (!value) return fail("wdpm_get_option: null argument");
+  if (key == WDPM_OPT_SIGNED_ZERO_SAFE) *value = x->signed_zero_safe ? 1 : 0;
+  else if (key == WDPM_OPT_DEM32) *value = x->code.q ? 1 : 0;
+  else return fail("wdpm_get_option: unknown option %d", key);
   return 0;
 }
 
 int wdpm_set_option(wdpm_ctx *x, int32_t key, int64_t value) {
-  if (key != WDPM_OPT_SIGNED_ZERO_SAFE) return fail("wdpm_set_option: unknown option %d", key);
-  x->signed_zero_safe = value != 0;
+  if (key == WDPM_OPT_SIGNED_ZERO_SAFE) {
+    x->signed_zero_safe = value != 0;
+  } else if (key == WDPM_OPT_DEM32) {
+    /* switching it on is honoured only for a DEM that passed the device's bit-for-bit check */
+    x->code.q = (value != 0 && x->dem32_encodable) ? x->d_dem32 : nullptr;
+  } else {
+    return fail("wdpm_set_option: unknown option %d", key);
+  }
   return 0;
 }
 
@@ -364,7 +411,7 @@ int wdpm_iterate(wdpm_ctx *x, int32_t n_iter) {
       x->launches += 1;
       it++;                      /* this launch was two iterations */
     } else if (x->kernel == WDPM_KERNEL_FUSED || x->kernel == WDPM_KERNEL_FUSED2 || x->kernel == WDPM_KERNEL_FUSED2W) {
-      HIP_TRY(wdpm_launch_fused(x->p.module, x->d_w[x->cur], x->d_w[x->cur ^ 1], x->d_dem, x->g, x->p.chunk_rows,
+      HIP_TRY(wdpm_launch_fused(x->p.module, x->d_w[x->cur], x->d_w[x->cur ^ 1], x->d_dem, x->code, x->g, x->p.chunk_rows,
                                 x->signed_zero_safe ? 1 : 0, x->d_scal, x->stream));
       x->cur ^= 1;
       x->launches += 1;
@@ -401,13 +448,13 @@ int wdpm_iterate_overlapped(wdpm_ctx *x, int32_t n_iter, int32_t top_rows, int32
   const int szs = x->signed_zero_safe ? 1 : 0;
   HIP_TRY(hipEventRecord(x->ev_fork, x->stream));               /* w_in is complete here */
   if (t_last >= 0)
-    HIP_TRY(wdpm_launch_fused_rows(x->p.module, w_in, w_out, x->d_dem, x->g, 0, t_last, x->p.chunk_rows, szs,
+    HIP_TRY(wdpm_launch_fused_rows(x->p.module, w_in, w_out, x->d_dem, x->code, x->g, 0, t_last, x->p.chunk_rows, szs,
                                    x->d_scal, x->stream));
   if (b_first < rows)
-    HIP_TRY(wdpm_launch_fused_rows(x->p.module, w_in, w_out, x->d_dem, x->g, b_first - 2, rows - 1, x->p.chunk_rows,
+    HIP_TRY(wdpm_launch_fused_rows(x->p.module, w_in, w_out, x->d_dem, x->code, x->g, b_first - 2, rows - 1, x->p.chunk_rows,
                                    szs, x->d_scal, x->stream));
   HIP_TRY(hipStreamWaitEvent(x->side, x->ev_fork, 0));
-  HIP_TRY(wdpm_launch_fused_rows(x->p.module, w_in, w_out, x->d_dem, x->g, t_last >= 0 ? t_last - 1 : 0,
+  HIP_TRY(wdpm_launch_fused_rows(x->p.module, w_in, w_out, x->d_dem, x->code, x->g, t_last >= 0 ? t_last - 1 : 0,
                                  b_first < rows ? b_first - 1 : rows - 1, x->p.chunk_rows, szs, x->d_scal, x->side));
   HIP_TRY(hipEventRecord(x->ev_join, x->side));
   x->pending_join = true;

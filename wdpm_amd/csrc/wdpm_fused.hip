@@ -217,10 +217,20 @@ __device__ __forceinline__ void stage(double (&W)[7][3], const double (&D)[7][3]
 #define WDPM_FUSED_MIN_WAVES 2   /* waves per SIMD the register allocator must leave room for */
 #endif
 
-template <int MODULE, bool SZ_SAFE>
+/* raw registers of the row prefetch.  DEM32: the dem rows arrive as 32-bit codes — interior waves
+ * fetch a lane's three columns with one 12-byte load (qi), edge waves column by column (qe).
+ * Only the members an instantiation uses exist. */
+typedef int wdpm_i3 __attribute__((ext_vector_type(3)));
+struct Prefetched {
+  double NW[3][3], ND[3][3];
+  wdpm_i3 qi[3];
+  int qe[3][3];
+};
+
+template <int MODULE, bool SZ_SAFE, bool DEM32>
 __global__ void __launch_bounds__(256, WDPM_FUSED_MIN_WAVES)
 fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout,
-                       const double *__restrict__ dem, const SlabGeom g, const int nstrips,
+                       const double *__restrict__ dem, const DemCode code, const SlabGeom g, const int nstrips,
                        const int nitems, const int H, const int A0, const int out_last,
                        double *__restrict__ totaldrain) {
   const int lane = threadIdx.x & 63;
@@ -293,6 +303,9 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
     int voff[3];
 #pragma unroll
     for (int j = 0; j < 3; j++) voff[j] = 8 * (EDGE ? (colb + j < g.ncp ? colb + j : g.ncp - 1) : colb);
+    int qoff[3];                     // the same for the 4-byte dem codes
+#pragma unroll
+    for (int j = 0; j < 3; j++) qoff[j] = voff[j] / 2;
 
     // Prefetch of the three rows starting at r0 into raw registers.  The loads are issued with
     // inline asm (saddr form: wave-uniform row base in SGPRs + a per-lane byte offset) so that
@@ -300,39 +313,61 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
     // `s_waitcnt vmcnt(9)` (the 9 stores of the step are the only younger memory operations).
     // Left to the compiler the loads get sunk next to their consumer or guarded by vmcnt(0), which
     // exposes a full memory round trip per step.  The registers are not read before wait_rows().
-    auto prefetch = [&](double (&NW)[3][3], double (&ND)[3][3], const int r0) {
+    auto prefetch = [&](Prefetched &P, const int r0) {
 #pragma unroll
       for (int i = 0; i < 3; i++) {
         int r = r0 + i;
         if (EDGE) r = r < g.rows ? r : g.rows - 1;
         const double *bw = win + (size_t)r * pitch;     // wave-uniform
         const double *bd = dem + (size_t)r * pitch;
+        const int *bq = code.q + (size_t)r * pitch;
         if (!EDGE) {
-          asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(NW[i][0]) : "v"(voff[0]), "s"(bw) : "memory");
-          asm volatile("global_load_dwordx2 %0, %1, %2 offset:8" : "=v"(NW[i][1]) : "v"(voff[0]), "s"(bw) : "memory");
-          asm volatile("global_load_dwordx2 %0, %1, %2 offset:16" : "=v"(NW[i][2]) : "v"(voff[0]), "s"(bw) : "memory");
-          asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(ND[i][0]) : "v"(voff[0]), "s"(bd) : "memory");
-          asm volatile("global_load_dwordx2 %0, %1, %2 offset:8" : "=v"(ND[i][1]) : "v"(voff[0]), "s"(bd) : "memory");
-          asm volatile("global_load_dwordx2 %0, %1, %2 offset:16" : "=v"(ND[i][2]) : "v"(voff[0]), "s"(bd) : "memory");
+          asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(P.NW[i][0]) : "v"(voff[0]), "s"(bw) : "memory");
+          asm volatile("global_load_dwordx2 %0, %1, %2 offset:8" : "=v"(P.NW[i][1]) : "v"(voff[0]), "s"(bw) : "memory");
+          asm volatile("global_load_dwordx2 %0, %1, %2 offset:16" : "=v"(P.NW[i][2]) : "v"(voff[0]), "s"(bw) : "memory");
+          if (DEM32) {
+            asm volatile("global_load_dwordx3 %0, %1, %2" : "=v"(P.qi[i]) : "v"(qoff[0]), "s"(bq) : "memory");
+          } else {
+            asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(P.ND[i][0]) : "v"(voff[0]), "s"(bd) : "memory");
+            asm volatile("global_load_dwordx2 %0, %1, %2 offset:8" : "=v"(P.ND[i][1]) : "v"(voff[0]), "s"(bd) : "memory");
+            asm volatile("global_load_dwordx2 %0, %1, %2 offset:16" : "=v"(P.ND[i][2]) : "v"(voff[0]), "s"(bd) : "memory");
+          }
         } else {
 #pragma unroll
           for (int j = 0; j < 3; j++) {
-            asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(NW[i][j]) : "v"(voff[j]), "s"(bw) : "memory");
-            asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(ND[i][j]) : "v"(voff[j]), "s"(bd) : "memory");
+            asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(P.NW[i][j]) : "v"(voff[j]), "s"(bw) : "memory");
+            if (DEM32) asm volatile("global_load_dword %0, %1, %2" : "=v"(P.qe[i][j]) : "v"(qoff[j]), "s"(bq) : "memory");
+            else asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(P.ND[i][j]) : "v"(voff[j]), "s"(bd) : "memory");
           }
         }
       }
     };
     // the wait that makes the prefetched registers readable; every register is an in/out operand so
     // no use can be scheduled above it.  YOUNGER = memory operations issued after the loads.
+#define WDPM_WAIT_W "+v"(P.NW[0][0]), "+v"(P.NW[0][1]), "+v"(P.NW[0][2]), "+v"(P.NW[1][0]), "+v"(P.NW[1][1]), \
+                    "+v"(P.NW[1][2]), "+v"(P.NW[2][0]), "+v"(P.NW[2][1]), "+v"(P.NW[2][2])
 #define WDPM_WAIT_ROWS(YOUNGER)                                                                        \
-  asm volatile("s_waitcnt vmcnt(" #YOUNGER ")"                                                         \
-               : "+v"(NW[0][0]), "+v"(NW[0][1]), "+v"(NW[0][2]), "+v"(NW[1][0]), "+v"(NW[1][1]),       \
-                 "+v"(NW[1][2]), "+v"(NW[2][0]), "+v"(NW[2][1]), "+v"(NW[2][2]), "+v"(ND[0][0]),       \
-                 "+v"(ND[0][1]), "+v"(ND[0][2]), "+v"(ND[1][0]), "+v"(ND[1][1]), "+v"(ND[1][2]),       \
-                 "+v"(ND[2][0]), "+v"(ND[2][1]), "+v"(ND[2][2])                                        \
-               :                                                                                       \
-               : "memory")
+  do {                                                                                                 \
+    if (!DEM32)                                                                                        \
+      asm volatile("s_waitcnt vmcnt(" #YOUNGER ")"                                                     \
+                   : WDPM_WAIT_W, "+v"(P.ND[0][0]), "+v"(P.ND[0][1]), "+v"(P.ND[0][2]), "+v"(P.ND[1][0]), \
+                     "+v"(P.ND[1][1]), "+v"(P.ND[1][2]), "+v"(P.ND[2][0]), "+v"(P.ND[2][1]),           \
+                     "+v"(P.ND[2][2])                                                                  \
+                   :                                                                                   \
+                   : "memory");                                                                        \
+    else if (!EDGE)                                                                                    \
+      asm volatile("s_waitcnt vmcnt(" #YOUNGER ")"                                                     \
+                   : WDPM_WAIT_W, "+v"(P.qi[0]), "+v"(P.qi[1]), "+v"(P.qi[2])                          \
+                   :                                                                                   \
+                   : "memory");                                                                        \
+    else                                                                                               \
+      asm volatile("s_waitcnt vmcnt(" #YOUNGER ")"                                                     \
+                   : WDPM_WAIT_W, "+v"(P.qe[0][0]), "+v"(P.qe[0][1]), "+v"(P.qe[0][2]), "+v"(P.qe[1][0]), \
+                     "+v"(P.qe[1][1]), "+v"(P.qe[1][2]), "+v"(P.qe[2][0]), "+v"(P.qe[2][1]),           \
+                     "+v"(P.qe[2][2])                                                                  \
+                   :                                                                                   \
+                   : "memory");                                                                        \
+  } while (0)
 
     // the three staged rows [rb, rb+2] from LDS to HBM: 9 unconditional stores
     auto store_rows = [&](const int rb) {
@@ -351,15 +386,16 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
       __builtin_amdgcn_wave_barrier();
     };
 
-    auto step = [&](const int n, double (&NW)[3][3], double (&ND)[3][3]) {
+    auto step = [&](const int n, Prefetched &P) {
       // consume the prefetched rows into window slots 4..6; the device DEM already holds +inf for
       // NODATA cells, so only edge waves have anything to mask (outside the slab: dem=+inf, w=0)
 #pragma unroll
       for (int i = 0; i < 3; i++)
 #pragma unroll
         for (int j = 0; j < 3; j++) {
-          W[4 + i][j] = NW[i][j];
-          D[4 + i][j] = ND[i][j];
+          W[4 + i][j] = P.NW[i][j];
+          if (DEM32) D[4 + i][j] = dem32_decode(EDGE ? P.qe[i][j] : P.qi[i][j], code.k0, code.D, code.rD);
+          else D[4 + i][j] = P.ND[i][j];
         }
       if (EDGE) {
 #pragma unroll
@@ -374,7 +410,7 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
         }
       }
       // always issued (the last trips re-read clamped / following rows and drop them)
-      prefetch(NW, ND, A + 3 * (n + 1));
+      prefetch(P, A + 3 * (n + 1));
       // the rows the previous step staged in LDS go out now, behind the new loads and ahead of a
       // whole step of arithmetic (+1 % over storing at the end of the step); n = 0 has none: dump
       store_rows(A + 3 * (n - 1) - 4);
@@ -409,12 +445,13 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
         for (int j = 0; j < 3; j++) { W[k][j] = W[k + 3][j]; D[k][j] = D[k + 3][j]; }
     };
 
-    double NW[3][3], ND[3][3];
-    prefetch(NW, ND, A);
+    Prefetched P;
+    prefetch(P, A);
     WDPM_WAIT_ROWS(0);
-    for (int n = 0; n < nsteps; n++) step(n, NW, ND);
+    for (int n = 0; n < nsteps; n++) step(n, P);
     store_rows(A + 3 * (nsteps - 1) - 4);      // the last step's rows
 #undef WDPM_WAIT_ROWS
+#undef WDPM_WAIT_W
   };
   if (edge) march(std::true_type{});
   else march(std::false_type{});
@@ -874,13 +911,13 @@ __global__ void dpp_probe_kernel(int *out) {
 /* Number of waves of the fused kernel the whole chip holds at once (CUs x blocks/CU x 4 waves),
  * from the occupancy API; cached per module.  All work items of a launch are made resident
  * together — one round, no tail — so the item count is sized to this. */
-template <int MODULE, bool SZ_SAFE>
+template <int MODULE, bool SZ_SAFE, bool DEM32 = false>
 static int resident_waves() {
   static int cached = 0;
   if (cached) return cached;
   int dev = 0, cus = 256, blocks = 2;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, fused_iteration_kernel<MODULE, SZ_SAFE>, 256, 0) != hipSuccess || blocks < 1)
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, fused_iteration_kernel<MODULE, SZ_SAFE, DEM32>, 256, 0) != hipSuccess || blocks < 1)
     blocks = 2;
   cached = cus * blocks * 4;
   return cached;
@@ -992,16 +1029,16 @@ hipError_t wdpm_launch_fused2w(const double *w_in, double *w_out, const double *
   return hipGetLastError();
 }
 
-hipError_t wdpm_launch_fused(int module, const double *w_in, double *w_out, const double *dem,
+hipError_t wdpm_launch_fused(int module, const double *w_in, double *w_out, const double *dem, const DemCode &code,
                              const SlabGeom &g, int chunk_rows, int signed_zero_safe, double *totaldrain,
                              hipStream_t s) {
-  return wdpm_launch_fused_rows(module, w_in, w_out, dem, g, 0, g.rows - 1, chunk_rows, signed_zero_safe,
+  return wdpm_launch_fused_rows(module, w_in, w_out, dem, code, g, 0, g.rows - 1, chunk_rows, signed_zero_safe,
                                 totaldrain, s);
 }
 
 /* one iteration restricted to the output rows [A0 + 2 (0 when A0 == 0), out_last]; A0 % 3 == 0 */
 hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out, const double *dem,
-                                  const SlabGeom &g, int A0, int out_last, int chunk_rows,
+                                  const DemCode &code, const SlabGeom &g, int A0, int out_last, int chunk_rows,
                                   int signed_zero_safe, double *totaldrain, hipStream_t s) {
   hipError_t e = dpp_selfcheck(s);
   if (e != hipSuccess) return e;
@@ -1009,8 +1046,13 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
   int nstrips = 1;
   if (g.ncp > kStripIn - kHaloR) nstrips = (g.ncp - (kStripIn - kHaloR) + kStripOut - 1) / kStripOut + 1;
   const bool fast = !signed_zero_safe;
+  // add / subtract with an encodable DEM: 20 B per cell-update instead of 24 (drain is latency-bound,
+  // not HBM-bound, and keeps the fp64 DEM: the decode would only add instructions)
+  const bool dem32 = fast && module != 2 && code.q != nullptr;
   int slots = module == 2 ? (fast ? resident_waves<2, false>() : resident_waves<2, true>())
-                          : fast ? resident_waves<0, false>() : resident_waves<0, true>();
+              : dem32     ? resident_waves<0, false, true>()
+              : fast      ? resident_waves<0, false>()
+                          : resident_waves<0, true>();
   {
     // The kernel is HBM-bound with ONE wave per SIMD already; a second wave per SIMD only adds
     // concurrent DRAM row streams and, on rasters too small to fill the chip, makes the dispatcher
@@ -1023,8 +1065,10 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
     // (>= 48 rows) for the 6-row warm-up of each not to eat the gain.
     static int env_pct = -1;
     if (env_pct < 0) { const char *e = getenv("WDPM_FILL_PERCENT"); env_pct = e ? atoi(e) : 0; }
+    // With the DEM as 32-bit codes the add kernel is in the same position: fewer bytes, nine decodes
+    // more per step - one wave per SIMD 1.34 ms per 16384^2 launch (no gain), two waves 1.23 ms.
     int pct = 50;
-    if (module == 2 && (long long)(out_last - A0 + 1) * nstrips >= 48LL * slots) pct = 100;
+    if ((module == 2 || dem32) && (long long)(out_last - A0 + 1) * nstrips >= 48LL * slots) pct = 100;
     if (env_pct > 0) pct = env_pct;
     if (pct > 0 && pct < 100) slots = slots * pct / 100;
   }
@@ -1036,12 +1080,14 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
   const int nitems = nstrips * nchunks;
   const dim3 grid(((nitems + 3) / 4 + 7) / 8 * 8), block(256);   // multiple of 8: see the XCD remap
   if (module == 2 && fast)
-    hipLaunchKernelGGL((fused_iteration_kernel<2, false>), grid, block, 0, s, w_in, w_out, dem, g, nstrips, nitems, H, A0, out_last, totaldrain);
+    hipLaunchKernelGGL((fused_iteration_kernel<2, false, false>), grid, block, 0, s, w_in, w_out, dem, code, g, nstrips, nitems, H, A0, out_last, totaldrain);
   else if (module == 2)
-    hipLaunchKernelGGL((fused_iteration_kernel<2, true>), grid, block, 0, s, w_in, w_out, dem, g, nstrips, nitems, H, A0, out_last, totaldrain);
+    hipLaunchKernelGGL((fused_iteration_kernel<2, true, false>), grid, block, 0, s, w_in, w_out, dem, code, g, nstrips, nitems, H, A0, out_last, totaldrain);
+  else if (dem32)
+    hipLaunchKernelGGL((fused_iteration_kernel<0, false, true>), grid, block, 0, s, w_in, w_out, dem, code, g, nstrips, nitems, H, A0, out_last, totaldrain);
   else if (fast)
-    hipLaunchKernelGGL((fused_iteration_kernel<0, false>), grid, block, 0, s, w_in, w_out, dem, g, nstrips, nitems, H, A0, out_last, totaldrain);
+    hipLaunchKernelGGL((fused_iteration_kernel<0, false, false>), grid, block, 0, s, w_in, w_out, dem, code, g, nstrips, nitems, H, A0, out_last, totaldrain);
   else
-    hipLaunchKernelGGL((fused_iteration_kernel<0, true>), grid, block, 0, s, w_in, w_out, dem, g, nstrips, nitems, H, A0, out_last, totaldrain);
+    hipLaunchKernelGGL((fused_iteration_kernel<0, true, false>), grid, block, 0, s, w_in, w_out, dem, code, g, nstrips, nitems, H, A0, out_last, totaldrain);
   return hipGetLastError();
 }

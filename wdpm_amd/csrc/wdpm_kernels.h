@@ -19,6 +19,24 @@ struct SlabGeom {
   double miss;   /* NODATA value */
 };
 
+/* The static DEM as 32-bit codes (4 B per cell instead of 8 in the iteration kernel's HBM traffic):
+ * dem[i] == dem32_decode(q[i]) BIT FOR BIT for every cell, verified on the device when the DEM is
+ * uploaded (wdpm_launch_dem_encode); NODATA is INT32_MIN.  Real DEMs are decimal text, i.e.
+ * v = k / 10^e for an integer k, and the decode is the correctly rounded quotient; a raster that
+ * is not of that form (any cell fails the check for e = 0..6) simply keeps the fp64 DEM. */
+struct DemCode {
+  const int *q;      /* rows x ncp codes, or nullptr when the raster is not encodable */
+  double k0;         /* integer offset: k = q + k0 */
+  double D, rD;      /* 10^e and its correctly rounded reciprocal */
+};
+
+/* smallest valid (finite) dem value, as an order-preserving uint64 key in *key (all ones: none) */
+hipError_t wdpm_launch_dem_min(const double *dem, size_t cells, unsigned long long *key, hipStream_t s);
+double wdpm_dem_key_to_double(unsigned long long key);
+/* q[i] = code of dem[i]; *bad |= 1 if any cell does not decode to exactly dem[i] */
+hipError_t wdpm_launch_dem_encode(const double *dem, size_t cells, double k0, double D, double rD, int *q,
+                                  unsigned long long *bad, hipStream_t s);
+
 /* in place: dem <= miss (or NaN) -> +inf.  Every other kernel expects the DEM in this form. */
 hipError_t wdpm_launch_mark_nodata(double *dem, size_t cells, double miss, hipStream_t s);
 /* one colour pass, in place (reference kernels add/subtract/ddrain, runoff.cl:137-183) */
@@ -27,7 +45,7 @@ hipError_t wdpm_launch_pass(int module, double *w, const double *dem, const Slab
 /* one whole iteration (9 passes) fused in one launch: w_in -> w_out (distinct buffers) */
 /* signed_zero_safe = 0 selects the faster add/subtract variant that is exact when the water raster
  * holds no -0.0 (wdpm_stencil.h::flow_add_nz) */
-hipError_t wdpm_launch_fused(int module, const double *w_in, double *w_out, const double *dem,
+hipError_t wdpm_launch_fused(int module, const double *w_in, double *w_out, const double *dem, const DemCode &code,
                              const SlabGeom &g, int chunk_rows, int signed_zero_safe, double *totaldrain,
                              hipStream_t s);
 /* two whole iterations of add / subtract in one launch (12 B of HBM traffic per cell-update) */
@@ -36,7 +54,7 @@ hipError_t wdpm_launch_fused2(const double *w_in, double *w_out, const double *d
 hipError_t wdpm_launch_fused2w(const double *w_in, double *w_out, const double *dem, const SlabGeom &g,
                                int chunk_rows, int signed_zero_safe, hipStream_t s);
 hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out, const double *dem,
-                                  const SlabGeom &g, int A0, int out_last, int chunk_rows,
+                                  const DemCode &code, const SlabGeom &g, int A0, int out_last, int chunk_rows,
                                   int signed_zero_safe, double *totaldrain, hipStream_t s);
 /* *flag |= 1 if any of the n doubles at p is -0.0 */
 hipError_t wdpm_launch_scan_negzero(const double *p, size_t n, unsigned long long *flag, hipStream_t s);

@@ -155,6 +155,79 @@ hipError_t wdpm_launch_flush_snapshot(double *w, double *old, size_t cells, doub
 }
 
 // ---------------------------------------------------------------------------------------------
+// DEM -> 32-bit codes (wdpm_kernels.h::DemCode), verified cell by cell with the decoder itself
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long ordered_key(const double v) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);      // monotone in v for all non-NaN doubles
+}
+
+double wdpm_dem_key_to_double(unsigned long long key) {
+  const unsigned long long b = (key >> 63) ? (key & 0x7fffffffffffffffull) : ~key;
+  union { unsigned long long u; double d; } pun;
+  pun.u = b;
+  return pun.d;
+}
+
+__global__ void __launch_bounds__(256)
+dem_min_kernel(const double *__restrict__ dem, size_t n, unsigned long long *key) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  unsigned long long m = ~0ull;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const double v = dem[i];
+    if (cell_valid(v)) {
+      const unsigned long long kx = ordered_key(v);
+      m = kx < m ? kx : m;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const unsigned long long o = __shfl_xor(m, off, 64);
+    m = o < m ? o : m;
+  }
+  if ((threadIdx.x & 63) == 0 && m != ~0ull) atomicMin(key, m);
+}
+
+hipError_t wdpm_launch_dem_min(const double *dem, size_t cells, unsigned long long *key, hipStream_t s) {
+  hipError_t e = hipMemsetAsync(key, 0xff, sizeof(unsigned long long), s);
+  if (e != hipSuccess || cells == 0) return e;
+  size_t blocks = (cells + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(dem_min_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dem, cells, key);
+  return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256)
+dem_encode_kernel(const double *__restrict__ dem, size_t n, double k0, double D, double rD, int *__restrict__ q,
+                  unsigned long long *bad) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  bool miss = false;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const double v = dem[i];
+    int code = (int)0x80000000;                              // NODATA (+inf on the device)
+    if (cell_valid(v)) {
+      const double kk = rint(v * D) - k0;
+      const bool fits = fabs(kk) < 2147483647.0;
+      code = fits ? (int)kk : 0;
+      const bool same = __double_as_longlong(dem32_decode(code, k0, D, rD)) == __double_as_longlong(v);
+      miss |= !(fits && same);
+    }
+    q[i] = code;
+  }
+  if (__ballot(miss) && (threadIdx.x & 63) == 0) atomicOr(bad, 1ull);
+}
+
+hipError_t wdpm_launch_dem_encode(const double *dem, size_t cells, double k0, double D, double rD, int *q,
+                                  unsigned long long *bad, hipStream_t s) {
+  hipError_t e = hipMemsetAsync(bad, 0, sizeof(unsigned long long), s);
+  if (e != hipSuccess || cells == 0) return e;
+  size_t blocks = (cells + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(dem_encode_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dem, cells, k0, D, rD, q, bad);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // does the raster hold a negative zero?  (decides which add/subtract stencil variant is exact)
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)

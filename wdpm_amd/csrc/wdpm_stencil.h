@@ -19,6 +19,18 @@
 
 #include <hip/hip_runtime.h>
 
+/* DEM code -> elevation (wdpm_kernels.h::DemCode).  n = q + k0 is an exact integer in fp64; n * rD is
+ * within an ulp of n / D and the two fused steps (a Newton correction on the residual n - q0 * D,
+ * which the FMA computes exactly) land on the correctly rounded quotient — but nothing rests on
+ * that argument: the encoder runs this very function on every cell and compares bits. */
+__device__ __forceinline__ double dem32_decode(const int q, const double k0, const double D, const double rD) {
+  const double n = (double)q + k0;
+  const double q0 = n * rD;
+  const double r = __builtin_fma(-q0, D, n);
+  const double v = __builtin_fma(r, rD, q0);
+  return q == (int)0x80000000 ? __builtin_inf() : v;
+}
+
 /* neighbour k = 0..7 in the reference's visiting order: rowloc outer -1..+1, colloc inner -1..+1,
  * centre skipped (WDPMCL.c:1940-1943) */
 __host__ __device__ constexpr int nb_dr(int k) { return (k < 3) ? -1 : (k < 5 ? 0 : 1); }
