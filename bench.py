@@ -40,17 +40,18 @@ def build_slab_inputs(lib, n, slab):
     return bd, bw
 
 
-def measured_traffic(n, world, kernel):
+def measured_traffic(n, world, kernel, dem32):
     """HBM bytes per fused-kernel launch from the committed rocprofv3 PMC passes (separate
     --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command, gfx950 x2 FETCH correction,
     calibrated on kernels of known byte count: profiles/).  Only for the configuration they
-    were taken on; otherwise null."""
+    were taken on; otherwise null.  With the DEM streamed as 32-bit codes the kernel moves 20 B per
+    cell-update, i.e. LESS than the 24 algorithmic bytes `achieved` is priced at."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
             t = json.load(f)
         if t["size"] == n and t["n_gpus"] == world and kernel in ("auto", "fused"):
-            return t["hbm_bytes_per_launch"]
+            return t["dem32" if dem32 else "fp64_dem"]["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
     return None
@@ -189,6 +190,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     launches, kernel_ms = solver.ctx.timing()
+    dem32 = bool(solver.ctx.get_option(wdpm_amd.OPT_DEM32)) and args.module == "add"
 
     if rank == 0:
         cells = float(n) * n
@@ -210,7 +212,9 @@ def main():
                        "exchange_every": args.exchange_every if world > 1 else None,
                        "max_diff_m": max_diff},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n, world, args.kernel),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n, world, args.kernel, dem32),
+                         "dem": "32-bit codes, verified lossless on upload (20 B of HBM traffic per cell-update)" if dem32
+                                else "fp64 (24 B of HBM traffic per cell-update)",
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_CELL_UPDATE * own_cells,
                          "kernel_ms_per_iteration": iter_ms, "launches": launches,
                          "job_frac": value * ALGO_BYTES_PER_CELL_UPDATE / 1e9 / (HBM_PEAK_GBS * world)},
