@@ -174,8 +174,9 @@ int  wdpm_group_drain_stats(wdpm_group *grp, double *diffdrain, double *final_su
  *   (4 bytes per cell-update of HBM traffic instead of 8).  Switched on by wdpm_upload when the device
  *   has verified, cell by cell and bit for bit, that the DEM is k / 10^e with 32-bit k (DEMs read
  *   from decimal text are); results are identical either way.  Setting 0 forces the fp64 DEM,
- *   setting 1 is honoured only for a DEM that passed the check.  WDPM_DEM32=0 in the environment
- *   disables the encoding altogether.  The CPU restatement reports 0. */
+ *   setting 1 is honoured only for a DEM that passed the check; the kernel then uses the codes on
+ *   launches large enough for them to pay (>= 4096^2 or so), setting 2 on launches of any size.  WDPM_DEM32=0 in the environment
+ *   disables the encoding altogether, WDPM_DEM32=2 makes 2 the default.  The CPU restatement reports 0. */
 enum { WDPM_OPT_SIGNED_ZERO_SAFE = 1, WDPM_OPT_DEM32 = 2 };
 int wdpm_get_option(wdpm_ctx *ctx, int32_t key, int64_t *value);
 int wdpm_set_option(wdpm_ctx *ctx, int32_t key, int64_t value);

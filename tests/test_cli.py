@@ -119,6 +119,20 @@ def test_hip_cli_baseline_configs(workdir, golden):
     param_file(HIP_CLI, golden, workdir)
 
 
+@pytest.mark.gpu
+def test_hip_cli_with_dem_codes_forced(workdir, golden):
+    """basin5 is too small for the DEM codes to pay, so the library would not use them: WDPM_DEM32=2
+    forces the code-streaming kernel and the reference's answers must not move"""
+    env = dict(os.environ, WDPM_DEM32="2")
+    for key, outfile in (("val_add10", "a10.asc"), ("cfg2_add300_k1000", "a300.asc")):
+        g = golden[key]
+        p = subprocess.run([HIP_CLI] + g["args"], cwd=workdir, capture_output=True, text=True, timeout=600, env=env)
+        assert p.returncode == 0, p.stderr
+        blocks, summary = parse_report(p.stdout)
+        assert blocks == g["blocks"] and summary == g["summary"]
+        assert file_sha(os.path.join(workdir, outfile)) == g["out_sha256"]
+
+
 def multi_device(exe, golden, cwd, devices):
     """WDPM_DEVICES spreads the raster over several contexts of one process (row blocks, halo copies):
     reports and rasters must not change"""

@@ -58,7 +58,7 @@ def _compare_with_oracle(hip, oracle, module, R, C, seed, iters, kernel, chunk=0
             # random_case rounds elevations to 4 decimals: the device finds them encodable by itself
             encodable = dem_digits is not None and bool((dem > miss).any())
             assert g.get_option(wdpm_amd.OPT_DEM32) == int(encodable)
-            g.set_option(wdpm_amd.OPT_DEM32, dem32)
+            g.set_option(wdpm_amd.OPT_DEM32, 2 if dem32 else 0)      # 2: also on launches this small
             assert g.get_option(wdpm_amd.OPT_DEM32) == int(bool(dem32) and encodable)
         for n in iters:
             if thres is not None:
@@ -124,6 +124,8 @@ def test_dem_code_edge_cases(hip, oracle, name):
     with hip.context(**kw) as g, oracle.context(**kw) as o:
         g.upload(bd, bw)
         o.upload(bd, bw)
+        assert g.get_option(wdpm_amd.OPT_DEM32) == want
+        g.set_option(wdpm_amd.OPT_DEM32, 2)                           # honoured only if the DEM passed the check
         assert g.get_option(wdpm_amd.OPT_DEM32) == want
         g.iterate(12)
         o.iterate(12)

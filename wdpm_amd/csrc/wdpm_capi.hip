@@ -130,7 +130,7 @@ int wdpm_create(wdpm_ctx **out, const wdpm_params *p) {
   x->ms = 0.0;
   x->d_dem = x->d_w[0] = x->d_w[1] = x->d_old = nullptr;
   x->d_scal = nullptr; x->d_bits = nullptr; x->h_pin = nullptr;
-  x->d_dem32 = nullptr; x->code = DemCode{nullptr, 0.0, 1.0, 1.0}; x->dem32_encodable = false;
+  x->d_dem32 = nullptr; x->code = DemCode{nullptr, 0.0, 1.0, 1.0, 0}; x->dem32_encodable = false;
   x->h_sum[0] = x->h_sum[1] = nullptr; x->ev_sum[0] = x->ev_sum[1] = nullptr;
   x->own_stream = true;
   x->side = nullptr; x->ev_fork = nullptr; x->ev_join = nullptr; x->pending_join = false;
@@ -234,7 +234,7 @@ static int encode_dem(wdpm_ctx *x) {
     memcpy(&bad, x->h_pin, sizeof bad);
     if (!bad) {
       x->dem32_encodable = true;
-      x->code = DemCode{x->d_dem32, k0, D, rD};
+      x->code = DemCode{x->d_dem32, k0, D, rD, (env && atoi(env) == 2) ? 1 : 0};   /* WDPM_DEM32=2: on launches of any size */
       break;
     }
   }
@@ -326,6 +326,7 @@ int wdpm_set_option(wdpm_ctx *x, int32_t key, int64_t value) {
   } else if (key == WDPM_OPT_DEM32) {
     /* switching it on is honoured only for a DEM that passed the device's bit-for-bit check */
     x->code.q = (value != 0 && x->dem32_encodable) ? x->d_dem32 : nullptr;
+    x->code.force = value == 2;   /* 2: also on launches too small for the codes to pay (tests) */
   } else {
     return fail("wdpm_set_option: unknown option %d", key);
   }

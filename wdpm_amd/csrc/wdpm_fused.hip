@@ -1052,7 +1052,7 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
   // the wave's own latency chain is the limit and the nine decodes per step cost 3-5 % (size sweep in
   // profiles/r01: 512^2 - 3072^2 slower with codes, 4096^2 and up 5-12 % faster).
   const bool big = (long long)(out_last - A0 + 1) * nstrips >= 48LL * resident_waves<0, false, true>();
-  const bool dem32 = fast && module != 2 && code.q != nullptr && big;
+  const bool dem32 = fast && module != 2 && code.q != nullptr && (big || code.force);
   int slots = module == 2 ? (fast ? resident_waves<2, false>() : resident_waves<2, true>())
               : dem32     ? resident_waves<0, false, true>()
               : fast      ? resident_waves<0, false>()

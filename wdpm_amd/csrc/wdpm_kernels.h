@@ -28,6 +28,7 @@ struct DemCode {
   const int *q;      /* rows x ncp codes, or nullptr when the raster is not encodable */
   double k0;         /* integer offset: k = q + k0 */
   double D, rD;      /* 10^e and its correctly rounded reciprocal */
+  int force;         /* use the codes on launches of any size (tests); normally only where they pay */
 };
 
 /* smallest valid (finite) dem value, as an order-preserving uint64 key in *key (all ones: none) */
