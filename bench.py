@@ -57,11 +57,43 @@ def measured_traffic(n, world, kernel, dem32):
     return None
 
 
+def reference_baseline(n, iters):
+    """The UNMODIFIED reference's serial functions (runoffs() on its own double** globals, driven in
+    the loop order of WDPMCL.c:1097-1103) from oracle/_ref/libwdpm_ref.so, which oracle/Makefile
+    builds from the sources where they lie under /root/reference and which travels to the GPU box as
+    a binary.  None if that library is not there or does not load."""
+    import ctypes as C
+    import wdpm_amd
+    so = os.path.join(ROOT, "oracle", "_ref", "libwdpm_ref.so")
+    try:
+        ref = C.CDLL(so)
+        ref.ref_setup.argtypes = [C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_int]
+        ref.ref_iterate.argtypes = [C.c_int, C.c_int]
+    except (OSError, AttributeError):
+        return None
+    dem = wdpm_amd.load_hip().synth_dem(n, n)
+    bd = np.full((n + 2, n + 2), MISSING)
+    bd[1:-1, 1:-1] = dem
+    bw = np.where(bd > MISSING, ADD_M, 0.0)
+    ref.ref_setup(n, n, MISSING, bd.ctypes.data, bw.ctypes.data, 0.0, 0, 0)
+    ref.ref_iterate(0, 1)
+    t = time.perf_counter()
+    ref.ref_iterate(0, iters)
+    dt = time.perf_counter() - t
+    return {"value": n * n * iters / dt, "unit": "cell-updates/s", "cores": 1, "kind": "reference",
+            "sample": f"runoffs() of the unmodified src/WDPMCL.c (oracle/_ref/libwdpm_ref.so), synthetic {n}x{n} "
+                      f"all-wet add 100 mm, {iters} iterations, {dt:.1f} s"}
+
+
 def cpu_baseline(n=4096, iters=32):
-    """The CPU oracle (bit-equal port of the reference's serial path) timed on one host core on a
-    bounded sample of the same workload.  A reported baseline, never the product path."""
+    """The reference's own serial code if its prebuilt library is present (kind "reference"), else the
+    CPU oracle (bit-equal port of it, kind "port"), timed on one host core on a bounded sample of the
+    same workload.  A reported baseline, never the product path."""
     import subprocess
     import wdpm_amd
+    ref = reference_baseline(n, 24)
+    if ref is not None:
+        return ref
     so = os.path.join(ROOT, "oracle", "_build", "libwdpm_oracle.so")
     if not os.path.exists(so):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "oracle"], stdout=subprocess.DEVNULL)
