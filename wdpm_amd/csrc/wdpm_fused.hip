@@ -9,7 +9,8 @@
  *  - A wave64 is the unit of work; waves never synchronise with each other (no barriers; LDS is
  *    only a wave-private transpose buffer for the stores).  Lane m owns raster columns
  *    c0+3m .. c0+3m+2, so a wave covers a 192-column strip and a 64-lane row load is one
- *    contiguous 1536-byte segment; one wave per SIMD already saturates HBM.
+ *    contiguous 1536-byte segment.  Waves per SIMD: one for add/subtract on the fp64 DEM (HBM-bound
+ *    already), two for drain (latency-bound) and for add/subtract on the DEM codes below.
  *  - The wave marches down a chunk of rows with a 7-row window held in registers (dem + water,
  *    3 columns per lane).  Each step loads 3 new rows and applies, in this order, row alignment
  *    oi=1 to rows 3n..3n+2, oi=2 to rows 3n-2..3n, oi=3 to rows 3n-4..3n-2 — a skew that respects
@@ -26,11 +27,15 @@
  *    neighbour this makes ht_diff -inf/NaN, so `ht_diff > 0` is false with no extra test
  *    (WDPMCL.c:1944); as a centre the gate `dem < +inf` replaces `bigdem > missingvalue` (:1099).
  *
+ *  - DEM32: the static DEM can be streamed as 32-bit codes q with dem == (q + k0) / 10^e bit for bit
+ *    (verified per cell at upload by the decoder used here, wdpm_stencil.h::dem32_decode): 12 bytes
+ *    per lane and row in one global_load_dwordx3, 20 B of HBM traffic per cell-update instead of 24.
  *  - Memory operations are unconditional and fixed in number per step (prefetch by inline-asm
  *    loads one step ahead, exact s_waitcnt; stores transposed through LDS to 512-byte contiguous
  *    non-temporal writes, issued at the top of the following step).
  *
- * Results are bit-identical to the serial reference: same operands, same order, fp64, no FMA.
+ * Results are bit-identical to the serial reference: same operands, same order, fp64, no FMA in
+ * the stencil (the DEM decode uses two, on values it has been verified to reproduce exactly).
  * The file also holds the opt-in two-iterations-per-launch kernels (fused2, fused2w).
  */
 #include "wdpm_kernels.h"
