@@ -1,5 +1,5 @@
 #!/bin/bash
-# raster-size sweep of the add kernel with the shipped defaults (profiles/r01/README.md)
+# raster-size sweep of the add kernel with the shipped defaults, DEM codes on and off (profiles/r01/size_sweep.txt)
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 for n in 512 1024 2048 3072 4096 6144 8192 12288 16384; do
   steps=$(( 400000000 / (n * n / 1000 + 1000) )); [ $steps -gt 3000 ] && steps=3000; [ $steps -lt 100 ] && steps=100
