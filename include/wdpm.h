@@ -142,7 +142,9 @@ int wdpm_timing_get(wdpm_ctx *ctx, int64_t *launches, double *ms);
 /* copy `nrows` rows of the CURRENT water raster from slab-local row `src_row` of `src` to row
  * `dst_row` of `dst` (same raster width).  Device to device on the HIP back-end (peer copy over
  * xGMI when the contexts live on different GPUs), ordered after everything queued on either
- * context.  This is the halo refresh primitive of single-process multi-GPU runs (wdpm_group_*). */
+ * context and before anything queued on either afterwards — on the devices (stream events); the
+ * call does not wait for the copy.  This is the halo refresh primitive of single-process
+ * multi-GPU runs (wdpm_group_*). */
 int wdpm_copy_rows(wdpm_ctx *dst, int32_t dst_row, wdpm_ctx *src, int32_t src_row, int32_t nrows);
 
 /* -- a raster spread over several GPUs of one process (what WDPMCL uses when WDPM_GPUS > 1) ------

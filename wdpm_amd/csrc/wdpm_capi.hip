@@ -62,6 +62,7 @@ struct wdpm_ctx {
   hipStream_t side;
   hipEvent_t ev_fork, ev_join;
   bool pending_join;
+  hipEvent_t ev_copy[2];        /* wdpm_copy_rows: [0] "my rows are produced" as source, [1] "the copy has read them" as destination */
   /* stencil timing */
   std::vector<EventPair> pending;
   std::vector<EventPair> pool;
@@ -133,7 +134,7 @@ int wdpm_create(wdpm_ctx **out, const wdpm_params *p) {
   x->d_dem32 = nullptr; x->code = DemCode{nullptr, 0.0, 1.0, 1.0, 0}; x->dem32_encodable = false;
   x->h_sum[0] = x->h_sum[1] = nullptr; x->ev_sum[0] = x->ev_sum[1] = nullptr;
   x->own_stream = true;
-  x->side = nullptr; x->ev_fork = nullptr; x->ev_join = nullptr; x->pending_join = false;
+  x->side = nullptr; x->ev_fork = nullptr; x->ev_join = nullptr; x->pending_join = false; x->ev_copy[0] = x->ev_copy[1] = nullptr;
   const size_t bytes = x->cells * sizeof(double);
   hipError_t e = hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&x->side, hipStreamNonBlocking);
@@ -167,6 +168,8 @@ void wdpm_destroy(wdpm_ctx *x) {
   if (x->side) { (void)hipStreamSynchronize(x->side); (void)hipStreamDestroy(x->side); }
   if (x->ev_fork) (void)hipEventDestroy(x->ev_fork);
   if (x->ev_join) (void)hipEventDestroy(x->ev_join);
+  for (int i = 0; i < 2; i++)
+    if (x->ev_copy[i]) (void)hipEventDestroy(x->ev_copy[i]);
   for (auto &ep : x->pending) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
   for (auto &ep : x->pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
   (void)hipFree(x->d_dem); (void)hipFree(x->d_w[0]); (void)hipFree(x->d_w[1]); (void)hipFree(x->d_old);
@@ -296,19 +299,25 @@ int wdpm_copy_rows(wdpm_ctx *dst, int32_t dst_row, wdpm_ctx *src, int32_t src_ro
       dst_row + nrows > dst->g.rows || src_row + nrows > src->g.rows)
     return fail("wdpm_copy_rows: bad row range");
   if (nrows == 0) return 0;
-  /* everything queued on the source must have produced the rows, everything queued on the
-   * destination must be done with the rows being overwritten; the copy itself is synchronous
-   * with respect to the host so that the caller may launch on either context afterwards */
+  /* Ordered on the device, never on the host: the copy runs on the destination's stream behind
+   * everything queued there (its kernels are done with the rows being overwritten), after an event
+   * that marks the source's queue (its kernels have produced the rows); the source's later work in
+   * turn waits for the copy to have read them.  With N devices in a chain the halo refresh is then
+   * 2(N-1) enqueues and no host round trip. */
   if (bind(src)) return 1;                       /* also joins a pending overlapped interior launch */
-  HIP_TRY(hipStreamSynchronize(src->stream));
+  if (!src->ev_copy[0]) HIP_TRY(hipEventCreateWithFlags(&src->ev_copy[0], hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(src->ev_copy[0], src->stream));
   if (bind(dst)) return 1;
-  HIP_TRY(hipStreamSynchronize(dst->stream));
+  if (!dst->ev_copy[1]) HIP_TRY(hipEventCreateWithFlags(&dst->ev_copy[1], hipEventDisableTiming));
+  HIP_TRY(hipStreamWaitEvent(dst->stream, src->ev_copy[0], 0));
   const size_t bytes = (size_t)nrows * src->g.ncp * sizeof(double);
   double *d = dst->d_w[dst->cur] + (size_t)dst_row * dst->g.ncp;
   const double *s = src->d_w[src->cur] + (size_t)src_row * src->g.ncp;
   if (src->p.device == dst->p.device) HIP_TRY(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToDevice, dst->stream));
   else HIP_TRY(hipMemcpyPeerAsync(d, dst->p.device, s, src->p.device, bytes, dst->stream));
-  HIP_TRY(hipStreamSynchronize(dst->stream));
+  HIP_TRY(hipEventRecord(dst->ev_copy[1], dst->stream));
+  HIP_TRY(hipSetDevice(src->p.device));
+  HIP_TRY(hipStreamWaitEvent(src->stream, dst->ev_copy[1], 0));
   return 0;
 }
 
