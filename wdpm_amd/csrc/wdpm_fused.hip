@@ -1056,7 +1056,7 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
   // ... and only pays on launches big enough for two waves per SIMD (see below): at one wave per SIMD
   // the wave's own latency chain is the limit and the nine decodes per step cost 3-5 % (size sweep in
   // profiles/r01: 512^2 - 3072^2 slower with codes, 4096^2 and up 5-12 % faster).
-  const bool big = (long long)(out_last - A0 + 1) * nstrips >= 48LL * resident_waves<0, false, true>();
+  const bool big = (long long)(out_last - A0 + 1) * nstrips >= 36LL * resident_waves<0, false, true>();
   const bool dem32 = fast && module != 2 && code.q != nullptr && (big || code.force);
   int slots = module == 2 ? (fast ? resident_waves<2, false>() : resident_waves<2, true>())
               : dem32     ? resident_waves<0, false, true>()
@@ -1071,13 +1071,17 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
     // The drain variant is different: 16 instructions per neighbour step on one dependent chain per
     // lane leave it latency-bound (59 % VALU issue at one wave per SIMD), and a second wave per SIMD
     // fills the bubbles: +21 % at 8192^2, +30 % at 16384^2 - as long as the chunks stay tall enough
-    // (>= 48 rows) for the 6-row warm-up of each not to eat the gain.
+    // for the 6-row warm-up of each not to eat the gain.
     static int env_pct = -1;
     if (env_pct < 0) { const char *e = getenv("WDPM_FILL_PERCENT"); env_pct = e ? atoi(e) : 0; }
     // With the DEM as 32-bit codes the add kernel is in the same position: fewer bytes, nine decodes
     // more per step - one wave per SIMD 1.34 ms per 16384^2 launch (no gain), two waves 1.23 ms.
+    // Thresholds from tools/threshold_sweep.sh and tools/slab_sweep.sh (profiles/r01): chunk height at
+    // two waves per SIMD >= 36 rows for the DEM-code add kernel (3072^2 still loses, 3600^2 gains 12 %),
+    // >= 18 rows for drain (+11 % on a 1055 x 8190 slab, +15 % at 3072^2, a wash at 2048^2).
     int pct = 50;
-    if ((module == 2 || dem32) && (long long)(out_last - A0 + 1) * nstrips >= 48LL * slots) pct = 100;
+    if (dem32 && big) pct = 100;
+    if (module == 2 && (long long)(out_last - A0 + 1) * nstrips >= 18LL * slots) pct = 100;
     if (env_pct > 0) pct = env_pct;
     if (pct > 0 && pct < 100) slots = slots * pct / 100;
   }
