@@ -137,7 +137,11 @@ int wdpm_create(wdpm_ctx **out, const wdpm_params *p) {
   x->side = nullptr; x->ev_fork = nullptr; x->ev_join = nullptr; x->pending_join = false; x->ev_copy[0] = x->ev_copy[1] = nullptr;
   const size_t bytes = x->cells * sizeof(double);
   hipError_t e = hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking);
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&x->side, hipStreamNonBlocking);
+  /* the side stream carries the interior launch of wdpm_iterate_overlapped: lowest priority, so that
+   * the boundary launches on the main stream (whose rows a neighbour is waiting for) get the CUs first */
+  int prio_least = 0, prio_greatest = 0;
+  if (e == hipSuccess) e = hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+  if (e == hipSuccess) e = hipStreamCreateWithPriority(&x->side, hipStreamNonBlocking, prio_least);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&x->ev_fork, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&x->ev_join, hipEventDisableTiming);
   if (e == hipSuccess) e = hipMalloc(&x->d_dem, bytes);
