@@ -460,6 +460,13 @@ int wdpm_iterate_overlapped(wdpm_ctx *x, int32_t n_iter, int32_t top_rows, int32
   const double *w_in = x->d_w[x->cur];
   double *w_out = x->d_w[x->cur ^ 1];
   const int szs = x->signed_zero_safe ? 1 : 0;
+  /* stencil timing of this iteration: from here on the main stream to the end of the interior launch
+   * on the side stream (the longest of the three) */
+  if (x->pending.size() >= 256 && fold_timing(x)) return 1;
+  EventPair ep;
+  if (!x->pool.empty()) { ep = x->pool.back(); x->pool.pop_back(); }
+  else { HIP_TRY(hipEventCreate(&ep.a)); HIP_TRY(hipEventCreate(&ep.b)); }
+  HIP_TRY(hipEventRecord(ep.a, x->stream));
   HIP_TRY(hipEventRecord(x->ev_fork, x->stream));               /* w_in is complete here */
   if (t_last >= 0)
     HIP_TRY(wdpm_launch_fused_rows(x->p.module, w_in, w_out, x->d_dem, x->code, x->g, 0, t_last, x->p.chunk_rows, szs,
@@ -470,6 +477,8 @@ int wdpm_iterate_overlapped(wdpm_ctx *x, int32_t n_iter, int32_t top_rows, int32
   HIP_TRY(hipStreamWaitEvent(x->side, x->ev_fork, 0));
   HIP_TRY(wdpm_launch_fused_rows(x->p.module, w_in, w_out, x->d_dem, x->code, x->g, t_last >= 0 ? t_last - 1 : 0,
                                  b_first < rows ? b_first - 1 : rows - 1, x->p.chunk_rows, szs, x->d_scal, x->side));
+  HIP_TRY(hipEventRecord(ep.b, x->side));
+  x->pending.push_back(ep);
   HIP_TRY(hipEventRecord(x->ev_join, x->side));
   x->pending_join = true;
   x->cur ^= 1;
