@@ -133,10 +133,10 @@ def test_hip_cli_with_dem_codes_forced(workdir, golden):
         assert file_sha(os.path.join(workdir, outfile)) == g["out_sha256"]
 
 
-def multi_device(exe, golden, cwd, devices):
+def multi_device(exe, golden, cwd, devices, **extra_env):
     """WDPM_DEVICES spreads the raster over several contexts of one process (row blocks, halo copies):
     reports and rasters must not change"""
-    env = dict(os.environ, WDPM_DEVICES=devices, WDPM_EXCHANGE_EVERY="3")
+    env = dict(os.environ, WDPM_DEVICES=devices, WDPM_EXCHANGE_EVERY="3", **extra_env)
     for key, outfile in (("val_add10", "a10.asc"), ("val_drain", "a10d.asc"), ("val_sub10", "a10s.asc")):
         g = golden[key]
         p = subprocess.run([exe] + g["args"], cwd=cwd, capture_output=True, text=True, timeout=1500, env=env)
@@ -197,6 +197,12 @@ def test_cli_three_contexts_on_oracle_backend(workdir, golden):
 @pytest.mark.gpu
 def test_hip_cli_four_contexts_on_one_gpu(workdir, golden):
     multi_device(HIP_CLI, golden, workdir, "0,0,0,0")
+
+
+@pytest.mark.gpu
+def test_hip_cli_three_contexts_with_dem_codes_forced(workdir, golden):
+    """every slab encodes its own rows of the DEM (own offset k0); forced on, since basin5 slabs are small"""
+    multi_device(HIP_CLI, golden, workdir, "0,0,0", WDPM_DEM32="2")
 
 
 @pytest.mark.gpu

@@ -422,9 +422,10 @@ def test_one_block_of_1000_iterations_at_8192(hip):
     assert abs(float(w1.sum()) - 0.1 * n * n) <= 1e-9 * 0.1 * n * n
 
 
+@pytest.mark.parametrize("dem32", [0, 2])
 @pytest.mark.parametrize("R,C,top,bottom", [(300, 500, 33, 44), (200, 700, 0, 40), (150, 180, 25, 0), (90, 400, 30, 30),
                                             (60, 200, 30, 30), (2079, 900, 33, 33)])
-def test_overlapped_iterate_equals_plain_iterate(hip, R, C, top, bottom):
+def test_overlapped_iterate_equals_plain_iterate(hip, R, C, top, bottom, dem32):
     """wdpm_iterate_overlapped: boundary rows first (two short launches), the interior on a side stream —
     same bits as the single launch, whatever the windows; too-small interiors fall back to one launch"""
     dem, water, miss = random_case(R + C, R, C)
@@ -433,6 +434,7 @@ def test_overlapped_iterate_equals_plain_iterate(hip, R, C, top, bottom):
     with hip.context(**kw) as a, hip.context(**kw) as b:
         a.upload(bd, bw)
         b.upload(bd, bw)
+        b.set_option(wdpm_amd.OPT_DEM32, dem32)     # the windowed launches with the fp64 DEM / with the codes
         for n in (1, 3, 4):
             a.iterate(n)
             b.iterate_overlapped(n, top, bottom)
