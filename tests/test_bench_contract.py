@@ -1,0 +1,44 @@
+"""bench.py prints ONE JSON line with the fields the driver reads (metric, value, unit, n_gpus, steps,
+warmup, ms_per_step, higher_is_better, scaling, vs_baseline, dtype, data, config.workload) plus the
+`roofline` and `cpu_baseline` objects; checked on a small raster so the test takes seconds."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def run_bench(*args):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True,
+                       timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_line_has_the_contract_fields():
+    d = run_bench("--size", "1024", "--steps", "7", "--warmup", "2")
+    assert d["metric"].startswith("cell-updates/sec on Add module") and d["unit"] == "cell-updates/s"
+    assert d["n_gpus"] == 1 and d["steps"] == 7 and d["warmup"] == 2
+    assert d["higher_is_better"] is True and d["scaling"] == "strong" and d["vs_baseline"] is None
+    assert d["dtype"] == "f64" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] > 0 and abs(d["value"] - 1024 * 1024 * 7 / (d["ms_per_step"] * 7e-3)) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0
+    assert r["traffic"] is None                         # PMC traffic is only quoted for the configuration it was measured on
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["value"] > 0 and c["unit"] == "cell-updates/s"
+    assert "iterations" in c["sample"]
+
+
+def test_bench_drain_line():
+    d = run_bench("--module", "drain", "--size", "1024", "--steps", "5", "--warmup", "1", "--drain-spinup", "20",
+                  "--no-cpu-baseline")
+    assert d["metric"].startswith("cell-updates/sec on Drain module") and d["value"] > 0 and "cpu_baseline" not in d
