@@ -215,6 +215,14 @@ def main():
     solver.ctx.timing_reset()
     t0 = time.perf_counter()
     max_diff = solver.run_block(args.steps, THRES) # exactly K timed steps
+    stats_s = None
+    if args.module == "drain":
+        # the drain module's per-block bookkeeping (WDPMCL.c:1257-1268) belongs to the block loop: |d totaldrain|
+        # and the sequential row-major volume sum (host, streamed down in chunks; rank-chained at N > 1)
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        solver.drain_stats()
+        stats_s = time.perf_counter() - ts
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -242,7 +250,8 @@ def main():
                                     f"{args.drain_spinup} iterations, one block of {args.steps} iterations"),
                        "kernel": args.kernel, "decomposition": f"row-block x{world}" if world > 1 else "single GPU",
                        "exchange_every": args.exchange_every if world > 1 else None,
-                       "max_diff_m": max_diff},
+                       "max_diff_m": max_diff,
+                       **({"drain_bookkeeping_ms_per_block": stats_s * 1e3} if stats_s is not None else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n, world, args.kernel, dem32),
                          "dem": "32-bit codes, verified lossless on upload (20 B of HBM traffic per cell-update)" if dem32

@@ -442,3 +442,39 @@ def test_overlapped_iterate_equals_plain_iterate(hip, R, C, top, bottom, dem32):
             assert bits_equal(a.download_rows(0, max(top, 1)), b.download_rows(0, max(top, 1)))
             assert n_bit_diff(a.download_water(), b.download_water()) == 0
         assert a.run_block(5, 1e-6) == b.run_block(5, 1e-6)
+
+
+def _volume_cases():
+    from test_seqsum_model import cases
+    return list(cases())
+
+
+@pytest.mark.parametrize("name", [c[0] for c in _volume_cases()])
+def test_volume_sum_is_the_sequential_sum(hip, name):
+    """wdpm_volume_partial (the drain module's `final_vol`, WDPMCL.c:1259-1266) evaluates the reference's
+    left-to-right fp64 sum in parallel on the device (tests/seqsum_model.py): bit-identical to the sequential
+    sum on ties, binade crossings, subnormals, negative / NaN / inf depths, chained start values"""
+    from seqsum_model import sequential_sum
+    x, start = next((c[1], c[2]) for c in _volume_cases() if c[0] == name)
+    C = 997
+    R = max(1, -(-len(x) // C))
+    rng = np.random.default_rng(11)
+    water = np.zeros(R * C)
+    water[:len(x)] = x
+    water = water.reshape(R, C)
+    dem = np.round(500 + rng.random((R, C)), 3)
+    miss = -99999.0
+    dem[rng.random((R, C)) < 0.03] = miss
+    water_at_nodata = np.where(dem > miss, water, -99999.0)      # what a drain run reads from an add run's output
+    bd, bw = pad(dem, water_at_nodata, miss)
+    valid = (bd > miss).ravel()
+    want = sequential_sum(bw.ravel()[valid], start)
+    with hip.context(module="add", nrows=R, ncols=C, missingvalue=miss) as g:
+        g.upload(bd, bw)
+        got = g.volume_partial(0, R + 2, start)
+        assert np.float64(got).view(np.uint64) == np.float64(want).view(np.uint64) or (np.isnan(got) and np.isnan(want)), \
+            (name, got, want)
+        # and row ranges chain: top half, then bottom half continued from it
+        half = (R + 2) // 2
+        chained = g.volume_partial(half, R + 2, g.volume_partial(0, half, start))
+        assert np.float64(chained).view(np.uint64) == np.float64(want).view(np.uint64) or np.isnan(want)

@@ -10,4 +10,4 @@ WDPM_DIST_BACKEND=gloo timeout -k 10 300 python -m torch.distributed.run --nnode
 echo "== same size, 1 rank"; timeout -k 10 120 python bench.py --size 4096 --steps 40 --warmup 4 --no-cpu-baseline 2>/dev/null | cut -c1-300
 echo "== config 3: chunk-height sweep at 4096^2 (rows per marching chunk -> cell-updates/s)"
 for h in 24 48 96 192 0 384 768; do echo -n "H=$h "; WDPM_CHUNK_ROWS=$h timeout -k 10 120 python bench.py --size 4096 --steps 200 --warmup 10 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%.4g cell-updates/s  kernel %.4f ms  frac %.3f' % (d['value'], d['roofline']['kernel_ms_per_iteration'], d['roofline']['frac']))"; done
-echo "== config 5: drain, 8192^2, 1 GPU"; timeout -k 10 300 python bench.py --module drain --size 8192 --steps 100 --warmup 5 --drain-spinup 200 --no-cpu-baseline 2>/dev/null | cut -c1-600
+echo "== config 5: drain, 8192^2, 1 GPU"; timeout -k 10 300 python bench.py --module drain --size 8192 --steps 1000 --warmup 5 --drain-spinup 200 --no-cpu-baseline 2>/dev/null | cut -c1-600

@@ -50,9 +50,10 @@ struct wdpm_ctx {
   double *d_scal;               /* [0] totaldrain, [1] olddrain */
   unsigned long long *d_bits;   /* max-diff reduction cell */
   double *h_pin;                /* pinned staging: 4 doubles */
-  double *h_sum[2];             /* pinned chunk buffers of wdpm_volume_partial (allocated on first use) */
-  hipEvent_t ev_sum[2];
-  std::vector<unsigned char> h_valid; /* bigdem > missingvalue per cell, kept only for wdpm_drain_stats */
+  double *d_sum_approx;         /* wdpm_volume_partial: per-chunk approximate sums, integer sums, binades, flags */
+  long long *d_sum_i;
+  int *d_sum_k;
+  unsigned *d_sum_flag;
   int kernel;                   /* resolved WDPM_KERNEL_* */
   bool signed_zero_safe;        /* a -0.0 depth was uploaded (or the caller asked): exact-zero stencil variant */
   int *d_dem32;                 /* the DEM as verified-lossless 32-bit codes (wdpm_kernels.h::DemCode) */
@@ -132,7 +133,7 @@ int wdpm_create(wdpm_ctx **out, const wdpm_params *p) {
   x->d_dem = x->d_w[0] = x->d_w[1] = x->d_old = nullptr;
   x->d_scal = nullptr; x->d_bits = nullptr; x->h_pin = nullptr;
   x->d_dem32 = nullptr; x->code = DemCode{nullptr, 0.0, 1.0, 1.0, 0}; x->dem32_encodable = false;
-  x->h_sum[0] = x->h_sum[1] = nullptr; x->ev_sum[0] = x->ev_sum[1] = nullptr;
+  x->d_sum_approx = nullptr; x->d_sum_i = nullptr; x->d_sum_k = nullptr; x->d_sum_flag = nullptr;
   x->own_stream = true;
   x->side = nullptr; x->ev_fork = nullptr; x->ev_join = nullptr; x->pending_join = false; x->ev_copy[0] = x->ev_copy[1] = nullptr;
   const size_t bytes = x->cells * sizeof(double);
@@ -179,10 +180,7 @@ void wdpm_destroy(wdpm_ctx *x) {
   (void)hipFree(x->d_dem); (void)hipFree(x->d_w[0]); (void)hipFree(x->d_w[1]); (void)hipFree(x->d_old);
   (void)hipFree(x->d_scal); (void)hipFree(x->d_bits); (void)hipFree(x->d_dem32);
   if (x->h_pin) (void)hipHostFree(x->h_pin);
-  for (int i = 0; i < 2; i++) {
-    if (x->h_sum[i]) (void)hipHostFree(x->h_sum[i]);
-    if (x->ev_sum[i]) (void)hipEventDestroy(x->ev_sum[i]);
-  }
+  (void)hipFree(x->d_sum_approx); (void)hipFree(x->d_sum_i); (void)hipFree(x->d_sum_k); (void)hipFree(x->d_sum_flag);
   if (x->own_stream && x->stream) (void)hipStreamDestroy(x->stream);
   delete x;
 }
@@ -258,10 +256,6 @@ int wdpm_upload(wdpm_ctx *x, const double *bigdem, const double *bigwater) {
   x->signed_zero_safe = false;
   if (note_negzero(x, 0, x->g.rows)) return 1;
   if (encode_dem(x)) return 1;
-  if (x->p.module == WDPM_DRAIN) {
-    x->h_valid.resize(x->cells);
-    for (size_t i = 0; i < x->cells; i++) x->h_valid[i] = bigdem[i] > x->g.miss;
-  }
   return 0;
 }
 
@@ -496,9 +490,8 @@ int wdpm_max_diff(wdpm_ctx *x, int32_t row_lo, int32_t row_hi, double *out) {
   return 0;
 }
 
-/* WDPMCL.c:1257-1268.  final_sum is the reference's sequential row-major sum; a parallel device
- * sum would round differently, so the raster comes to the host for it (drain module only, once
- * per block of iterations). */
+/* WDPMCL.c:1257-1268.  final_sum is the reference's sequential row-major sum (an ordinary parallel
+ * sum would round differently): wdpm_volume_partial evaluates exactly that sum on the device. */
 int wdpm_drain_stats(wdpm_ctx *x, double *diffdrain, double *final_sum) {
   if (bind(x)) return 1;
   if (diffdrain) {
@@ -510,40 +503,72 @@ int wdpm_drain_stats(wdpm_ctx *x, double *diffdrain, double *final_sum) {
   return 0;
 }
 
+/* The reference's sequential row-major sum over the valid cells of rows [row_lo, row_hi), continued
+ * from `start` - evaluated in parallel on the device, bit for bit the left-to-right fp64 sum
+ * (tests/seqsum_model.py explains why that is possible and models every step below).  Only chunks
+ * whose running sum comes too close to a power of two, or that hold an exact rounding tie or a
+ * negative / non-finite depth, are fetched and summed term by term. */
 int wdpm_volume_partial(wdpm_ctx *x, int32_t row_lo, int32_t row_hi, double start, double *sum) {
   if (row_lo < 0 || row_hi > x->g.rows || row_lo > row_hi || !sum) return fail("wdpm_volume_partial: bad row range");
-  if (x->h_valid.size() != x->cells) return fail("wdpm_volume_partial: no DEM has been uploaded to this drain context");
   if (bind(x)) return 1;
   const size_t first = (size_t)row_lo * x->g.ncp, n = (size_t)(row_hi - row_lo) * x->g.ncp;
-  /* the sum must be the reference's sequential one (a parallel sum rounds differently), so the host
-   * adds while the next chunk is on its way: two page-locked 8-MiB buffers, copies on the side
-   * stream behind everything queued on the context's stream */
-  const size_t chunk = (size_t)1 << 20;
-  if (!x->h_sum[0]) {
-    HIP_TRY(hipHostMalloc((void **)&x->h_sum[0], chunk * sizeof(double), hipHostMallocDefault));
-    HIP_TRY(hipHostMalloc((void **)&x->h_sum[1], chunk * sizeof(double), hipHostMallocDefault));
-    HIP_TRY(hipEventCreateWithFlags(&x->ev_sum[0], hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&x->ev_sum[1], hipEventDisableTiming));
+  const size_t nchunks = (n + kSeqSumChunk - 1) / kSeqSumChunk;
+  if (nchunks == 0) { *sum = start; return 0; }
+  const size_t cap = x->cells / kSeqSumChunk + 2;
+  if (!x->d_sum_approx) {
+    HIP_TRY(hipMalloc(&x->d_sum_approx, cap * sizeof(double)));
+    HIP_TRY(hipMalloc(&x->d_sum_i, cap * sizeof(long long)));
+    HIP_TRY(hipMalloc(&x->d_sum_k, cap * sizeof(int)));
+    HIP_TRY(hipMalloc(&x->d_sum_flag, cap * sizeof(unsigned)));
   }
-  HIP_TRY(hipEventRecord(x->ev_fork, x->stream));
-  HIP_TRY(hipStreamWaitEvent(x->side, x->ev_fork, 0));
-  const double *src = x->d_w[x->cur] + first;
-  const size_t nchunks = (n + chunk - 1) / chunk;
-  auto fetch = [&](size_t c) -> hipError_t {
-    const size_t off = c * chunk, len = n - off < chunk ? n - off : chunk;
-    hipError_t e = hipMemcpyAsync(x->h_sum[c & 1], src + off, len * sizeof(double), hipMemcpyDeviceToHost, x->side);
-    return e == hipSuccess ? hipEventRecord(x->ev_sum[c & 1], x->side) : e;
-  };
-  double s = start;
-  if (nchunks) HIP_TRY(fetch(0));
+  const double *w = x->d_w[x->cur] + first, *dem = x->d_dem + first;
+  std::vector<double> approx(nchunks), tw, td;
+  std::vector<unsigned> flag(nchunks);
+  std::vector<int> kexp(nchunks);
+  std::vector<long long> isum(nchunks);
+
+  /* pass A: ordinary per-chunk sums -> which binade each chunk's running sum will live in */
+  HIP_TRY(wdpm_launch_seqsum_a(w, dem, n, x->d_sum_approx, x->d_sum_flag, x->stream));
+  HIP_TRY(hipMemcpyAsync(approx.data(), x->d_sum_approx, nchunks * sizeof(double), hipMemcpyDeviceToHost, x->stream));
+  HIP_TRY(hipMemcpyAsync(flag.data(), x->d_sum_flag, nchunks * sizeof(unsigned), hipMemcpyDeviceToHost, x->stream));
+  HIP_TRY(hipStreamSynchronize(x->stream));
+  const bool start_ok = start >= 0.0 && start < __builtin_inf();
+  double prefix = start_ok ? start : 0.0;
+  size_t eligible = 0;
   for (size_t c = 0; c < nchunks; c++) {
-    HIP_TRY(hipEventSynchronize(x->ev_sum[c & 1]));
-    if (c + 1 < nchunks) HIP_TRY(fetch(c + 1));          /* the other buffer: summed one trip ago */
-    const size_t off = c * chunk, len = n - off < chunk ? n - off : chunk;
-    const double *w = x->h_sum[c & 1];
-    const unsigned char *ok = x->h_valid.data() + first + off;
+    const double lo = prefix, hi = prefix + approx[c];
+    prefix = hi;
+    kexp[c] = (int)0x80000000;
+    if (start_ok && !flag[c] && lo > 1e-290 && hi < 1e300) {
+      int e_lo, e_hi;
+      (void)frexp(lo * (1.0 - 1e-6), &e_lo);
+      (void)frexp(hi * (1.0 + 1e-6), &e_hi);
+      if (e_lo == e_hi) { kexp[c] = e_lo - 1; eligible++; }          /* 2^k <= running sum < 2^(k+1) all through the chunk */
+    }
+  }
+  /* pass B: exact integer sums in units of 2^(k-52) */
+  if (eligible) {
+    HIP_TRY(hipMemcpyAsync(x->d_sum_k, kexp.data(), nchunks * sizeof(int), hipMemcpyHostToDevice, x->stream));
+    HIP_TRY(wdpm_launch_seqsum_b(w, dem, n, x->d_sum_k, x->d_sum_i, x->d_sum_flag, x->stream));
+    HIP_TRY(hipMemcpyAsync(isum.data(), x->d_sum_i, nchunks * sizeof(long long), hipMemcpyDeviceToHost, x->stream));
+    HIP_TRY(hipMemcpyAsync(flag.data(), x->d_sum_flag, nchunks * sizeof(unsigned), hipMemcpyDeviceToHost, x->stream));
+    HIP_TRY(hipStreamSynchronize(x->stream));
+  }
+  /* chain: a chunk's integer sum is used only if its assumption holds for the ACTUAL running sum */
+  double s = start;
+  for (size_t c = 0; c < nchunks; c++) {
+    const int k = kexp[c];
+    if (k != (int)0x80000000 && !flag[c] && s >= ldexp(1.0, k)) {
+      const double s_new = s + ldexp((double)isum[c], k - 52);        /* exact: both are multiples of 2^(k-52) */
+      if (s_new < ldexp(1.0, k + 1)) { s = s_new; continue; }
+    }
+    const size_t off = c * kSeqSumChunk, len = n - off < (size_t)kSeqSumChunk ? n - off : (size_t)kSeqSumChunk;
+    tw.resize(len); td.resize(len);
+    HIP_TRY(hipMemcpyAsync(tw.data(), w + off, len * sizeof(double), hipMemcpyDeviceToHost, x->stream));
+    HIP_TRY(hipMemcpyAsync(td.data(), dem + off, len * sizeof(double), hipMemcpyDeviceToHost, x->stream));
+    HIP_TRY(hipStreamSynchronize(x->stream));
     for (size_t i = 0; i < len; i++)
-      if (ok[i]) s += w[i];
+      if (td[i] < __builtin_inf()) s += tw[i];                        /* the device DEM holds +inf for NODATA */
   }
   *sum = s;
   return 0;

@@ -38,6 +38,17 @@ double wdpm_dem_key_to_double(unsigned long long key);
 hipError_t wdpm_launch_dem_encode(const double *dem, size_t cells, double k0, double D, double rD, int *q,
                                   unsigned long long *bad, hipStream_t s);
 
+/* The reference's SEQUENTIAL volume sum (WDPMCL.c:1259-1266) evaluated in parallel, see
+ * tests/seqsum_model.py: chunks of kSeqSumChunk cells in row-major order.
+ *   pass A: approx[c] = ordinary sum of the valid cells of chunk c, dirty[c] = a negative / non-finite term
+ *   pass B: for chunks with kexp[c] != INT32_MIN, isum[c] = sum of round(x / 2^(kexp-52)) as int64,
+ *           tie[c] = some term lies exactly half way between two multiples of 2^(kexp-52) */
+constexpr int kSeqSumChunk = 65536;
+hipError_t wdpm_launch_seqsum_a(const double *w, const double *dem, size_t n, double *approx, unsigned *dirty,
+                                hipStream_t s);
+hipError_t wdpm_launch_seqsum_b(const double *w, const double *dem, size_t n, const int *kexp, long long *isum,
+                                unsigned *tie, hipStream_t s);
+
 /* in place: dem <= miss (or NaN) -> +inf.  Every other kernel expects the DEM in this form. */
 hipError_t wdpm_launch_mark_nodata(double *dem, size_t cells, double miss, hipStream_t s);
 /* one colour pass, in place (reference kernels add/subtract/ddrain, runoff.cl:137-183) */

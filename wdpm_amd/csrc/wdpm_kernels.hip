@@ -228,6 +228,75 @@ hipError_t wdpm_launch_dem_encode(const double *dem, size_t cells, double k0, do
 }
 
 // ---------------------------------------------------------------------------------------------
+// the sequential volume sum in parallel (tests/seqsum_model.py is the model and the proof sketch)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+seqsum_a_kernel(const double *__restrict__ w, const double *__restrict__ dem, size_t n, double *approx,
+                unsigned *dirty) {
+  __shared__ double part[4];
+  const size_t lo = (size_t)blockIdx.x * kSeqSumChunk, hi = lo + kSeqSumChunk < n ? lo + kSeqSumChunk : n;
+  double s = 0.0;
+  bool bad = false;
+  for (size_t i = lo + threadIdx.x; i < hi; i += 256)
+    if (cell_valid(dem[i])) {
+      const double v = w[i];
+      bad |= !(v >= 0.0) | (v == __builtin_inf());
+      s += v;
+    }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  const bool any_bad = __syncthreads_or(bad);
+  if (threadIdx.x == 0) {
+    approx[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+    dirty[blockIdx.x] = any_bad ? 1u : 0u;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+seqsum_b_kernel(const double *__restrict__ w, const double *__restrict__ dem, size_t n, const int *__restrict__ kexp,
+                long long *isum, unsigned *tie) {
+  __shared__ long long part[4];
+  const int k = kexp[blockIdx.x];
+  if (k == (int)0x80000000) return;                        // this chunk is summed term by term on the host
+  const size_t lo = (size_t)blockIdx.x * kSeqSumChunk, hi = lo + kSeqSumChunk < n ? lo + kSeqSumChunk : n;
+  long long q = 0;
+  bool half = false;
+  for (size_t i = lo + threadIdx.x; i < hi; i += 256)
+    if (cell_valid(dem[i])) {
+      const double t = __builtin_ldexp(w[i], 52 - k);        // exact scaling to units of u = 2^(k-52)
+      const double m = floor(t);
+      const double r = t - m;                                // exact
+      q += (long long)m + (r > 0.5 ? 1 : 0);
+      half |= r == 0.5;
+    }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = q;
+  const bool any_half = __syncthreads_or(half);
+  if (threadIdx.x == 0) {
+    isum[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+    tie[blockIdx.x] = any_half ? 1u : 0u;
+  }
+}
+
+hipError_t wdpm_launch_seqsum_a(const double *w, const double *dem, size_t n, double *approx, unsigned *dirty,
+                                hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  const unsigned blocks = (unsigned)((n + kSeqSumChunk - 1) / kSeqSumChunk);
+  hipLaunchKernelGGL(seqsum_a_kernel, dim3(blocks), dim3(256), 0, s, w, dem, n, approx, dirty);
+  return hipGetLastError();
+}
+
+hipError_t wdpm_launch_seqsum_b(const double *w, const double *dem, size_t n, const int *kexp, long long *isum,
+                                unsigned *tie, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  const unsigned blocks = (unsigned)((n + kSeqSumChunk - 1) / kSeqSumChunk);
+  hipLaunchKernelGGL(seqsum_b_kernel, dim3(blocks), dim3(256), 0, s, w, dem, n, kexp, isum, tie);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // does the raster hold a negative zero?  (decides which add/subtract stencil variant is exact)
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
