@@ -190,6 +190,21 @@ def test_hip_cli_lossless_checkpoint_resume(workdir, golden):
     lossless_resume(HIP_CLI, golden, workdir)
 
 
+def test_cli_threaded_host_passes(workdir, golden):
+    """the set-up / statistics / ArcASCII passes of big rasters run on several host threads; forced on for
+    basin5 (WDPM_HOST_PAR_MIN=1), reports and rasters must stay the reference's"""
+    env = dict(os.environ, WDPM_HOST_PAR_MIN="1", WDPM_IO_THREADS="5")
+    for key, outfile in (("cfg2_add300_k1000", "a300.asc"), ("val_add10", "a10.asc"), ("val_drain", "a10d.asc"),
+                         ("val_sub10", "a10s.asc")):
+        g = golden[key]
+        p = subprocess.run([ORACLE_CLI] + g["args"], cwd=workdir, capture_output=True, text=True, timeout=1500, env=env)
+        assert p.returncode == g["rc"], p.stderr
+        blocks, summary = parse_report(p.stdout)
+        assert blocks == g["blocks"] and summary == g["summary"]
+        assert hashlib.sha256(strip_timing(p.stdout).encode()).hexdigest() == g["report_sha256_nontiming"]
+        assert file_sha(os.path.join(workdir, outfile)) == g["out_sha256"]
+
+
 def test_cli_three_contexts_on_oracle_backend(workdir, golden):
     multi_device(ORACLE_CLI, golden, workdir, "0,0,0")
 

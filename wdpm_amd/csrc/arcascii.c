@@ -11,6 +11,9 @@
 #include <ctype.h>
 #include <pthread.h>
 #include <unistd.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -148,9 +151,14 @@ static const char *header_pair(const char *p, char *name, double *value) {
 }
 
 int asc_read_header(const char *path, asc_header *h) {
-  size_t len;
-  char *buf = slurp(path, &len);
-  if (!buf) return 1;
+  /* the six pairs sit in the first few hundred bytes: read 64 KiB, not the (multi-GB) file */
+  FILE *f = fopen(path, "rb");
+  if (!f) return 1;
+  char *buf = (char *)malloc(65536 + 1);
+  if (!buf) { fclose(f); return 1; }
+  const size_t got = fread(buf, 1, 65536, f);
+  fclose(f);
+  buf[got] = '\0';
   memset(h, 0, sizeof *h);
   const char *p = buf;
   for (int i = 0; i < 6 && p; i++) p = header_pair(p, h->name[i], &h->value[i]);
@@ -161,7 +169,8 @@ int asc_read_header(const char *path, asc_header *h) {
 /* ---- threads: big rasters are parsed / formatted by several host threads (WDPM_IO_THREADS, default
  * = online cores up to 16; small rasters stay on one thread) ------------------------------------ */
 static int io_threads(size_t cells) {
-  if (cells < (size_t)1 << 20) return 1;
+  const char *pm = getenv("WDPM_HOST_PAR_MIN");            /* cells below which the I/O stays on one thread (tests lower it) */
+  if (cells < (pm ? (size_t)atoll(pm) : (size_t)1 << 20)) return 1;
   const char *e = getenv("WDPM_IO_THREADS");
   long n = e ? atol(e) : sysconf(_SC_NPROCESSORS_ONLN);
   if (n > (e ? 16 : 8)) n = e ? 16 : 8;
@@ -207,16 +216,43 @@ static void *parse_slice(void *arg) {
   return NULL;
 }
 
+/* the text of a (possibly multi-GB) grid file: mapped read-only when the bytes after its end are
+ * readable zeros (file size not a multiple of the page size: the parsers rely on a terminating
+ * NUL), else read into memory */
+typedef struct { char *p; size_t len, maplen; } text_t;
+static int text_open(const char *path, text_t *t) {
+  t->p = NULL; t->len = t->maplen = 0;
+  const int fd = open(path, O_RDONLY);
+  if (fd >= 0) {
+    struct stat st;
+    const long page = sysconf(_SC_PAGESIZE);
+    if (fstat(fd, &st) == 0 && st.st_size > (off_t)(1 << 20) && page > 0 && st.st_size % page != 0) {
+      void *m = mmap(NULL, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+      if (m != MAP_FAILED) {
+        (void)madvise(m, (size_t)st.st_size, MADV_WILLNEED);
+        t->p = (char *)m; t->len = t->maplen = (size_t)st.st_size;
+      }
+    }
+    close(fd);
+  }
+  if (!t->p) t->p = slurp(path, &t->len);
+  return t->p ? 0 : 1;
+}
+static void text_close(text_t *t) {
+  if (t->maplen) munmap(t->p, t->maplen); else free(t->p);
+}
+
 int asc_read_grid(const char *path, int nrows, int ncols, double *dst) {
-  size_t len;
-  char *buf = slurp(path, &len);
-  if (!buf) return 1;
+  text_t text;
+  if (text_open(path, &text)) return 1;
+  const size_t len = text.len;
+  char *buf = text.p;
   const char *p = buf;
   char name[32];
   double dummy;
   for (int i = 0; i < 6 && p; i++) p = header_pair(p, name, &dummy);
   const size_t total = (size_t)nrows * ncols;
-  if (!p) { free(buf); return 0; }
+  if (!p) { text_close(&text); return 0; }
   const char *const textend = buf + len;
   int T = io_threads(total);
   parse_job jobs[16];
@@ -254,7 +290,7 @@ int asc_read_grid(const char *path, int nrows, int ncols, double *dst) {
     parse_job j = {p, textend, 0, 0, dst, total, 0};
     parse_slice(&j);
   }
-  free(buf);
+  text_close(&text);
   return 0;
 }
 

@@ -27,6 +27,7 @@
 #include <string.h>
 #include <sys/stat.h>
 #include <sys/time.h>
+#include <unistd.h>
 
 #include "../../include/wdpm.h"
 #include "arcascii.h"
@@ -305,6 +306,46 @@ typedef struct {
   int basincount, drainrow, draincol;
 } raster_state;
 
+/* ---- elementwise host passes over big rasters run on several threads (WDPM_IO_THREADS, default =
+ * online cores up to 8; rasters below 2^20 cells stay on one).  Only passes whose result does not
+ * depend on the order of evaluation: the reference's volume sums stay sequential. ---------------- */
+typedef void (*range_fn)(size_t lo, size_t hi, int tid, void *ctx);
+typedef struct { range_fn fn; void *ctx; size_t lo, hi; int tid; } range_job;
+static void *range_main(void *arg) {
+  range_job *j = (range_job *)arg;
+  j->fn(j->lo, j->hi, j->tid, j->ctx);
+  return NULL;
+}
+#define MAX_HOST_THREADS 16
+static int host_threads(size_t n) {
+  const char *pm = getenv("WDPM_HOST_PAR_MIN");            /* cells below which a pass stays on one thread (tests lower it) */
+  if (n < (pm ? (size_t)atoll(pm) : (size_t)1 << 20)) return 1;
+  const char *e = getenv("WDPM_IO_THREADS");
+  long t = e ? atol(e) : sysconf(_SC_NPROCESSORS_ONLN);
+  if (t > (e ? MAX_HOST_THREADS : 8)) t = e ? MAX_HOST_THREADS : 8;
+  return t < 1 ? 1 : (int)t;
+}
+/* fn(lo, hi, tid, ctx) over [0, n) cut into one contiguous range per thread (n units of `weight`
+ * cells each: cells or rows); returns the thread count */
+static int parallel_ranges_w(size_t n, size_t weight, range_fn fn, void *ctx) {
+  int T = host_threads(n * weight);
+  if ((size_t)T > n) T = n ? (int)n : 1;
+  if (T == 1) { fn(0, n, 0, ctx); return 1; }
+  pthread_t th[MAX_HOST_THREADS];
+  range_job job[MAX_HOST_THREADS];
+  int started = 0;
+  for (int t = 0; t < T; t++) {
+    job[t].fn = fn; job[t].ctx = ctx; job[t].tid = t;
+    job[t].lo = n / T * t; job[t].hi = t == T - 1 ? n : n / T * (t + 1);
+    if (pthread_create(&th[t], NULL, range_main, &job[t]) != 0) break;
+    started++;
+  }
+  for (int t = started; t < T; t++) range_main(&job[t]);          /* could not start it: do it here */
+  for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
+  return T;
+}
+static int parallel_ranges(size_t n, range_fn fn, void *ctx) { return parallel_ranges_w(n, 1, fn, ctx); }
+
 static double volume_where(const raster_state *s, double dem_above) {
   double v = 0;
   const size_t n = (size_t)s->R * s->C;
@@ -313,10 +354,18 @@ static double volume_where(const raster_state *s, double dem_above) {
   return v * s->cellarea;
 }
 
+typedef struct { raster_state *s; const run_config *c; int flag; long count[MAX_HOST_THREADS]; double mx[MAX_HOST_THREADS]; } pass_ctx;
+
+static void zero_water_range(size_t lo, size_t hi, int tid, void *ctx) {
+  pass_ctx *p = (pass_ctx *)ctx;
+  raster_state *s = p->s;
+  (void)tid;
+  for (size_t i = lo; i < hi; i++)
+    if (!p->flag || s->dem[i] > s->missing) s->water[i] = 0;
+}
 static void zero_water(raster_state *s, int valid_only) {
-  const size_t n = (size_t)s->R * s->C;
-  for (size_t i = 0; i < n; i++)
-    if (!valid_only || s->dem[i] > s->missing) s->water[i] = 0;
+  pass_ctx p = {.s = s, .flag = valid_only};
+  parallel_ranges((size_t)s->R * s->C, zero_water_range, &p);
 }
 
 /* water-file branch shared by add and subtract: returns 1 when an existing file was read */
@@ -335,21 +384,49 @@ static int load_or_create_water(const run_config *c, raster_state *s) {
   return 0;
 }
 
-static void apply_module_water(const run_config *c, raster_state *s) {
-  const size_t n = (size_t)s->R * s->C;
+static void apply_module_water_range(size_t lo, size_t hi, int tid, void *ctx) {
+  pass_ctx *p = (pass_ctx *)ctx;
+  raster_state *s = p->s;
+  const run_config *c = p->c;
+  (void)tid;
   if (c->module == WDPM_ADD) {
     const double add = c->addwater / 1000.0, rof = c->rof;          /* WDPMCL.c:419 */
-    for (size_t i = 0; i < n; i++)                                   /* :727-733 */
-      if (s->dem[i] > s->missing && s->water[i] > 0) s->water[i] += add;
-    for (size_t i = 0; i < n; i++)                                   /* :734-740 */
-      if (s->dem[i] > s->missing && s->water[i] <= 0) s->water[i] = add * rof;
+    /* the reference makes two passes (:727-733 then :734-740); per cell they amount to: a wet cell gets
+     * += add and - now being > 0 or not - is looked at again by the second test, exactly as here */
+    for (size_t i = lo; i < hi; i++)
+      if (s->dem[i] > s->missing) {
+        if (s->water[i] > 0) s->water[i] += add;
+        if (s->water[i] <= 0) s->water[i] = add * rof;
+      }
   } else if (c->module == WDPM_SUBTRACT) {
     const double sub = c->subtractwater / 1000;                      /* :475 */
-    for (size_t i = 0; i < n; i++)                                   /* :879-885 */
+    for (size_t i = lo; i < hi; i++)                                 /* :879-885 */
       if (s->dem[i] > s->missing) {
         const double d = s->water[i] - sub;
         s->water[i] = d > 0 ? d : 0;
       }
+  }
+}
+static void apply_module_water(const run_config *c, raster_state *s) {
+  pass_ctx p = {.s = s, .c = c};
+  parallel_ranges((size_t)s->R * s->C, apply_module_water_range, &p);
+}
+
+/* padded rows [lo, hi): border = (missing, 0), interior = the file rasters (WDPMCL.c:796-807) */
+static void pad_rows_range(size_t lo, size_t hi, int tid, void *ctx) {
+  raster_state *s = ((pass_ctx *)ctx)->s;
+  const size_t n = (size_t)s->C + 2;
+  (void)tid;
+  for (size_t i = lo; i < hi; i++) {
+    double *bd = s->bigdem + i * n, *bw = s->bigwater + i * n;
+    if (i == 0 || i == (size_t)s->R + 1) {
+      for (size_t j = 0; j < n; j++) { bd[j] = s->missing; bw[j] = 0; }
+      continue;
+    }
+    bd[0] = bd[n - 1] = s->missing;
+    bw[0] = bw[n - 1] = 0;
+    memcpy(bd + 1, s->dem + (i - 1) * s->C, (size_t)s->C * sizeof(double));
+    memcpy(bw + 1, s->water + (i - 1) * s->C, (size_t)s->C * sizeof(double));
   }
 }
 
@@ -400,8 +477,9 @@ static void prefer_lossless_scratch(const run_config *c, raster_state *s) {
 static void setup_module(const run_config *c, raster_state *s) {
   const int have_scratch_name = !is_null_name(c->scratch);
   int resumed = 0;
-  if (c->module == WDPM_ADD) s->initial_vol = volume_where(s, s->missing);      /* :656-664 (water is 0) */
-  if (c->module == WDPM_SUBTRACT) s->initial_vol = volume_where(s, 0.0);        /* :813-821 (dem > 0) */
+  /* :656-664 / :813-821 sum the water raster before anything has been read into it: every term is
+   * the +0.0 it was allocated with, so the sum is +0.0 without a pass over the raster */
+  if (c->module == WDPM_ADD || c->module == WDPM_SUBTRACT) s->initial_vol = 0.0 * s->cellarea;
   if (have_scratch_name) {
     if (file_exists(c->scratch)) {                                             /* resume, :668-673 */
       printf("%s\n", "           ");
@@ -431,12 +509,10 @@ static void setup_module(const run_config *c, raster_state *s) {
   }
   /* padded arrays, WDPMCL.c:796-807 */
   const int n = s->C + 2;
-  for (size_t i = 0; i < (size_t)(s->R + 2) * n; i++) { s->bigdem[i] = s->missing; s->bigwater[i] = 0; }
-  for (int i = 0; i < s->R; i++)
-    for (int j = 0; j < s->C; j++) {
-      s->bigdem[(size_t)(i + 1) * n + j + 1] = s->dem[(size_t)i * s->C + j];
-      s->bigwater[(size_t)(i + 1) * n + j + 1] = s->water[(size_t)i * s->C + j];
-    }
+  {
+    pass_ctx p = {.s = s};
+    parallel_ranges_w((size_t)s->R + 2, (size_t)n, pad_rows_range, &p);
+  }
   if (c->module == WDPM_DRAIN) {
     double mindrain = 100000000;                                               /* :1005-1017 */
     for (int i = 0; i < s->R + 2; i++)
@@ -459,14 +535,43 @@ static void setup_module(const run_config *c, raster_state *s) {
   iteration_headings(c->module);
 }
 
-static void unpad_water(raster_state *s, int mask_missing) {
-  const int n = s->C + 2;
-  for (int i = 0; i < s->R; i++)
-    for (int j = 0; j < s->C; j++) {
-      const size_t k = (size_t)i * s->C + j;
-      s->water[k] = s->bigwater[(size_t)(i + 1) * n + j + 1];
-      if (mask_missing && s->dem[k] <= s->missing) s->water[k] = s->missing;
+static void unpad_rows_range(size_t lo, size_t hi, int tid, void *ctx) {
+  pass_ctx *p = (pass_ctx *)ctx;
+  raster_state *s = p->s;
+  const size_t n = (size_t)s->C + 2;
+  (void)tid;
+  for (size_t i = lo; i < hi; i++)
+    for (size_t j = 0; j < (size_t)s->C; j++) {
+      const size_t k = i * s->C + j;
+      s->water[k] = s->bigwater[(i + 1) * n + j + 1];
+      if (p->flag && s->dem[k] <= s->missing) s->water[k] = s->missing;
     }
+}
+static void unpad_water(raster_state *s, int mask_missing) {
+  pass_ctx p = {.s = s, .flag = mask_missing};
+  parallel_ranges_w((size_t)s->R, (size_t)s->C, unpad_rows_range, &p);
+}
+
+/* counts and the maximum of the final statistics (WDPMCL.c:1394-1459): order-free, so threaded; the
+ * reference seeds the maximum with water[0][0] and lets `>` decide, so a NaN cell never wins unless it
+ * is that seed - kept by seeding every range with -inf and folding the ranges into water[0] in order */
+static void count_valid_range(size_t lo, size_t hi, int tid, void *ctx) {
+  pass_ctx *p = (pass_ctx *)ctx;
+  long c = 0;
+  for (size_t i = lo; i < hi; i++) c += p->s->dem[i] > p->s->missing;
+  p->count[tid] = c;
+}
+static void final_counts_range(size_t lo, size_t hi, int tid, void *ctx) {
+  pass_ctx *p = (pass_ctx *)ctx;
+  const raster_state *s = p->s;
+  long c = 0;
+  double mx = -INFINITY;
+  for (size_t i = lo; i < hi; i++) {
+    c += s->water[i] > 0.001 && s->dem[i] > s->missing;
+    if (s->water[i] > mx) mx = s->water[i];
+  }
+  p->count[tid] = c;
+  p->mx[tid] = mx;
 }
 
 /* devices to spread the raster over: WDPM_DEVICES=a,b,c | WDPM_GPUS=N (0..N-1) | WDPM_DEVICE=n | 0 */
@@ -652,8 +757,11 @@ int main(int argc, char **argv) {
   phase("read DEM");
   printf("%s\n", "           ");
   printf("%s\n", "           ");
-  for (size_t i = 0; i < ncell; i++)
-    if (st.dem[i] > st.missing) st.basincount++;                               /* :643-650 */
+  {
+    pass_ctx p = {.s = &st};
+    const int T = parallel_ranges(ncell, count_valid_range, &p);               /* :643-650 */
+    for (int t = 0; t < T; t++) st.basincount += (int)p.count[t];
+  }
 
   setup_module(&cfg, &st);
   phase("set-up (water file, module)");
@@ -726,10 +834,11 @@ int main(int argc, char **argv) {
   unpad_water(&st, 1);
   int watercount = 0;
   double watertotal = 0, final_vol = 0;
-  for (size_t i = 0; i < ncell; i++) {
-    if (st.water[i] > 0.001 && st.dem[i] > st.missing) watercount++;
+  pass_ctx fin = {.s = &st};
+  const int finT = parallel_ranges(ncell, final_counts_range, &fin);
+  for (int t = 0; t < finT; t++) watercount += (int)fin.count[t];
+  for (size_t i = 0; i < ncell; i++)                                           /* the sequential sum stays sequential */
     if (st.dem[i] > st.missing) watertotal += st.water[i];
-  }
   final_vol = watertotal * st.cellarea;
   const double meanwater = watertotal / ((float)watercount);
   const double waterfrac = (float)watercount / (float)st.basincount;
@@ -739,8 +848,8 @@ int main(int argc, char **argv) {
     draindepth = (drainvol / ((float)st.basincount * st.cellarea)) * 1000;
   }
   double maxdepth = st.water[0];
-  for (size_t i = 0; i < ncell; i++)
-    if (st.water[i] > maxdepth) maxdepth = st.water[i];
+  for (int t = 0; t < finT; t++)
+    if (fin.mx[t] > maxdepth) maxdepth = fin.mx[t];
   maxdepth = maxdepth * 1000;
 
   phase("final statistics");
