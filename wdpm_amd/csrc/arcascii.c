@@ -173,7 +173,7 @@ static int io_threads(size_t cells) {
   if (cells < (pm ? (size_t)atoll(pm) : (size_t)1 << 20)) return 1;
   const char *e = getenv("WDPM_IO_THREADS");
   long n = e ? atol(e) : sysconf(_SC_NPROCESSORS_ONLN);
-  if (n > (e ? 16 : 8)) n = e ? 16 : 8;
+  if (n > 16) n = 16;
   return n < 1 ? 1 : (int)n;
 }
 

@@ -307,7 +307,7 @@ typedef struct {
 } raster_state;
 
 /* ---- elementwise host passes over big rasters run on several threads (WDPM_IO_THREADS, default =
- * online cores up to 8; rasters below 2^20 cells stay on one).  Only passes whose result does not
+ * online cores up to 16; rasters below 2^20 cells stay on one).  Only passes whose result does not
  * depend on the order of evaluation: the reference's volume sums stay sequential. ---------------- */
 typedef void (*range_fn)(size_t lo, size_t hi, int tid, void *ctx);
 typedef struct { range_fn fn; void *ctx; size_t lo, hi; int tid; } range_job;
@@ -322,7 +322,7 @@ static int host_threads(size_t n) {
   if (n < (pm ? (size_t)atoll(pm) : (size_t)1 << 20)) return 1;
   const char *e = getenv("WDPM_IO_THREADS");
   long t = e ? atol(e) : sysconf(_SC_NPROCESSORS_ONLN);
-  if (t > (e ? MAX_HOST_THREADS : 8)) t = e ? MAX_HOST_THREADS : 8;
+  if (t > MAX_HOST_THREADS) t = MAX_HOST_THREADS;
   return t < 1 ? 1 : (int)t;
 }
 /* fn(lo, hi, tid, ctx) over [0, n) cut into one contiguous range per thread (n units of `weight`
