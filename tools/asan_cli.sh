@@ -1,0 +1,19 @@
+#!/bin/bash
+# AddressSanitizer + UBSan run of the WDPMCL host code (CPU build against the oracle back-end; GPU ASan
+# is not available on the pool): plain, threaded host passes, three contexts, checkpoint sidecar + resume,
+# drain, subtract.  Prints any sanitizer report; silence = clean.   usage: bash tools/asan_cli.sh
+set -e
+R=$(cd "$(dirname "$0")/.." && pwd); W=$(mktemp -d); trap 'rm -rf $W' EXIT
+gcc -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -ffp-contract=off -o $W/WDPMCL_asan \
+    $R/wdpm_amd/csrc/wdpmcl_main.c $R/wdpm_amd/csrc/arcascii.c $R/oracle/wdpm_oracle.c $R/wdpm_amd/csrc/synth.c \
+    $R/wdpm_amd/csrc/wdpm_group.c -lpthread -lm
+cd $W; zcat $R/tests/golden/basin5.asc.gz > basin5.asc
+run() { echo "== $*"; env "$@" > out.txt 2> err.txt || echo "exit code $?"; grep -E "ERROR|runtime error|leak" err.txt || true; }
+run ./WDPMCL_asan add basin5.asc NULL a.asc s.asc 100 1.0 1.0 0 0 0.005 2000
+run WDPM_HOST_PAR_MIN=1 WDPM_IO_THREADS=6 ./WDPMCL_asan add basin5.asc NULL a.asc s.asc 100 1.0 1.0 0 0 0.005 2000
+run WDPM_DEVICES=0,0,0 WDPM_EXCHANGE_EVERY=2 ./WDPMCL_asan add basin5.asc NULL a.asc s.asc 100 1.0 1.0 0 0 0.005 2000
+run WDPM_SCRATCH_BINARY=1 ./WDPMCL_asan add basin5.asc NULL a.asc s.asc 100 1.0 1.0 0 0 0.005 2000
+run WDPM_SCRATCH_BINARY=1 ./WDPMCL_asan add basin5.asc NULL a2.asc s.asc 100 1.0 1.0 0 0 0.005 1000
+run ./WDPMCL_asan drain basin5.asc a.asc d.asc NULL 1.0 1.0 0 0 0.005 1000
+run ./WDPMCL_asan subtract basin5.asc a.asc sub.asc NULL 10 1.0 0 0 0.005 1000
+echo done
