@@ -1,5 +1,5 @@
 #!/bin/bash
-# AddressSanitizer + UBSan run of the WDPMCL host code (CPU build against the oracle back-end; GPU ASan
+# AddressSanitizer + UBSan, then ThreadSanitizer, runs of the WDPMCL host code (CPU build against the oracle back-end; GPU ASan
 # is not available on the pool): plain, threaded host passes, three contexts, checkpoint sidecar + resume,
 # drain, subtract.  Prints any sanitizer report; silence = clean.   usage: bash tools/asan_cli.sh
 set -e
@@ -16,4 +16,10 @@ run WDPM_SCRATCH_BINARY=1 ./WDPMCL_asan add basin5.asc NULL a.asc s.asc 100 1.0 
 run WDPM_SCRATCH_BINARY=1 ./WDPMCL_asan add basin5.asc NULL a2.asc s.asc 100 1.0 1.0 0 0 0.005 1000
 run ./WDPMCL_asan drain basin5.asc a.asc d.asc NULL 1.0 1.0 0 0 0.005 1000
 run ./WDPMCL_asan subtract basin5.asc a.asc sub.asc NULL 10 1.0 0 0 0.005 1000
+# ThreadSanitizer on the threaded parts (checkpoint writer thread, threaded passes, threaded ArcASCII I/O)
+gcc -O1 -g -fsanitize=thread -ffp-contract=off -o $W/WDPMCL_tsan \
+    $R/wdpm_amd/csrc/wdpmcl_main.c $R/wdpm_amd/csrc/arcascii.c $R/oracle/wdpm_oracle.c $R/wdpm_amd/csrc/synth.c \
+    $R/wdpm_amd/csrc/wdpm_group.c -lpthread -lm
+echo "== tsan"; WDPM_HOST_PAR_MIN=1 WDPM_IO_THREADS=6 WDPM_SCRATCH_BINARY=1 ./WDPMCL_tsan add basin5.asc NULL a.asc s.asc 100 1.0 1.0 0 0 0.005 3000 > out.txt 2> err.txt || echo "exit code $?"
+grep -c "WARNING: ThreadSanitizer" err.txt || true
 echo done
