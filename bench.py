@@ -211,6 +211,8 @@ def main():
             torch.cuda.synchronize()
 
     solver.run_block(args.warmup, THRES)           # untimed warm-up steps
+    if world > 1:
+        solver.exchange()                          # the transport's first use (communicator set-up) is never timed
     sync()
     solver.ctx.timing_reset()
     t0 = time.perf_counter()
