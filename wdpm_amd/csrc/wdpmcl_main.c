@@ -824,7 +824,10 @@ int main(int argc, char **argv) {
   if (write_scratch) scratch_finish(&scratch);
   phase("wait for checkpoint writer");
 
-  double totaldrain = 0;
+  double totaldrain = 0, device_sum = 0;
+  /* watertotal of the final statistics (:1405-1412) is the same sequential row-major sum over the valid
+   * cells as the drain module's final_vol: the back-end evaluates it (the HIP one on the device, exactly) */
+  ABI_TRY(wdpm_group_drain_stats(ctx, NULL, &device_sum));
   ABI_TRY(wdpm_group_download_water(ctx, st.bigwater));
   if (cfg.module == WDPM_DRAIN) ABI_TRY(wdpm_group_get_totaldrain(ctx, &totaldrain));
   wdpm_group_destroy(ctx);
@@ -837,8 +840,7 @@ int main(int argc, char **argv) {
   pass_ctx fin = {.s = &st};
   const int finT = parallel_ranges(ncell, final_counts_range, &fin);
   for (int t = 0; t < finT; t++) watercount += (int)fin.count[t];
-  for (size_t i = 0; i < ncell; i++)                                           /* the sequential sum stays sequential */
-    if (st.dem[i] > st.missing) watertotal += st.water[i];
+  watertotal = device_sum;
   final_vol = watertotal * st.cellarea;
   const double meanwater = watertotal / ((float)watercount);
   const double waterfrac = (float)watercount / (float)st.basincount;
