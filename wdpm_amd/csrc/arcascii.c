@@ -324,6 +324,16 @@ static void *format_rows(void *arg) {
   return NULL;
 }
 
+typedef struct { FILE *f; fmt_job *jobs; int T, rc; } band_write;
+static void *write_band(void *arg) {
+  band_write *b = (band_write *)arg;
+  for (int t = 0; t < b->T && !b->rc; t++) {
+    if (b->jobs[t].len == (size_t)-1) b->rc = 1;
+    else if (b->jobs[t].len && fwrite(b->jobs[t].buf, 1, b->jobs[t].len, b->f) != b->jobs[t].len) b->rc = 1;
+  }
+  return NULL;
+}
+
 int asc_write_grid(const char *path, const asc_header *h, int nrows, int ncols, const double *src) {
   FILE *f = fopen(path, "w");
   if (!f) return 1;
@@ -342,30 +352,42 @@ int asc_write_grid(const char *path, const asc_header *h, int nrows, int ncols, 
   free(buf);
   const int T = io_threads((size_t)nrows * ncols);
   /* rows are formatted in bands; within a band each thread formats a contiguous run of rows into
-   * its own buffer and the buffers are written out in order */
+   * its own buffer and the buffers are written out in order - by a writer thread, while the
+   * formatters are already busy with the next band (two sets of buffers) */
   const int band = T * 64;
-  fmt_job jobs[16];
-  pthread_t th[16];
-  for (int t = 0; t < T; t++) { jobs[t].buf = NULL; jobs[t].cap = 0; jobs[t].src = src; jobs[t].ncols = ncols; }
-  for (int r0 = 0; r0 < nrows && !rc; r0 += band) {
+  fmt_job jobs[2][16];
+  pthread_t th[16], wth;
+  band_write bw[2];
+  int writing = -1;                                       /* set whose write is in flight, or -1 */
+  for (int k = 0; k < 2; k++)
+    for (int t = 0; t < T; t++) { jobs[k][t].buf = NULL; jobs[k][t].cap = 0; jobs[k][t].src = src; jobs[k][t].ncols = ncols; }
+  int set = 0;
+  for (int r0 = 0; r0 < nrows && !rc; r0 += band, set ^= 1) {
+    fmt_job *job = jobs[set];
     const int r1 = r0 + band < nrows ? r0 + band : nrows;
     const int per = (r1 - r0 + T - 1) / T;
     for (int t = 0; t < T; t++) {
-      jobs[t].row0 = r0 + t * per < r1 ? r0 + t * per : r1;
-      jobs[t].row1 = jobs[t].row0 + per < r1 ? jobs[t].row0 + per : r1;
+      job[t].row0 = r0 + t * per < r1 ? r0 + t * per : r1;
+      job[t].row1 = job[t].row0 + per < r1 ? job[t].row0 + per : r1;
     }
     if (T > 1) {
-      for (int t = 0; t < T; t++) pthread_create(&th[t], NULL, format_rows, &jobs[t]);
+      for (int t = 0; t < T; t++) pthread_create(&th[t], NULL, format_rows, &job[t]);
       for (int t = 0; t < T; t++) pthread_join(th[t], NULL);
     } else {
-      format_rows(&jobs[0]);
+      format_rows(&job[0]);
     }
-    for (int t = 0; t < T && !rc; t++) {
-      if (jobs[t].len == (size_t)-1) rc = 1;
-      else if (jobs[t].len && fwrite(jobs[t].buf, 1, jobs[t].len, f) != jobs[t].len) rc = 1;
+    if (writing >= 0) {                                   /* the previous band must be on its way before this one */
+      pthread_join(wth, NULL);
+      rc |= bw[writing].rc;
+      writing = -1;
     }
+    bw[set].f = f; bw[set].jobs = job; bw[set].T = T; bw[set].rc = 0;
+    if (T > 1 && !rc && pthread_create(&wth, NULL, write_band, &bw[set]) == 0) writing = set;
+    else if (!rc) { write_band(&bw[set]); rc |= bw[set].rc; }
   }
-  for (int t = 0; t < T; t++) free(jobs[t].buf);
+  if (writing >= 0) { pthread_join(wth, NULL); rc |= bw[writing].rc; }
+  for (int k = 0; k < 2; k++)
+    for (int t = 0; t < T; t++) free(jobs[k][t].buf);
   if (fclose(f) != 0) rc = 1;
   return rc;
 }
