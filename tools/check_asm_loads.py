@@ -1,52 +1,127 @@
 #!/usr/bin/env python3
-"""Static check of the fused kernel's inline-asm prefetch: between an asm `global_load` and the next
-asm `s_waitcnt vmcnt`, no instruction may read or overwrite the load's destination registers (the
-compiler does not know they are still in flight).  Usage: check_asm_loads.py <kernel.s>"""
+"""Static check of the fused kernels' inline-asm prefetch: on every control-flow path between an asm
+`global_load` and the next asm `s_waitcnt vmcnt`, no instruction may read or overwrite the load's
+destination registers (the compiler does not know they are still in flight).  Works on the basic-block
+graph of each kernel (labels, s_branch / s_cbranch_*, fall-through) with a forward "registers in
+flight" data-flow to a fixed point.  Usage: check_asm_loads.py <kernel.s>"""
 import re
 import sys
 
-lines = open(sys.argv[1]).read().splitlines()
-inflight = {}   # reg number -> line of the load
-bad = 0
-in_asm = False
-for ln, text in enumerate(lines, 1):
-    t = text.strip()
-    if t.startswith(";;#ASMSTART"):
-        in_asm = True
-        continue
-    if t.startswith(";;#ASMEND"):
-        in_asm = False
-        continue
-    if t.startswith("s_endpgm"):
-        if inflight:
-            print(f"line {ln}: kernel ends with loads never waited for"); bad += 1
-        inflight.clear()
-        continue
-    if not t or t.startswith((";", ".")) or t.endswith(":"):
-        continue
-    if in_asm and t.startswith("s_waitcnt vmcnt"):
-        inflight.clear()
-        continue
+LOAD = re.compile(r"global_load_dword(?:x[234])? ([va])(?:\[(\d+):(\d+)\]|(\d+))")
+
+
+def regs_of(t):
     regs = set()   # arch VGPR n -> n, accumulation VGPR n -> 1000 + n
     for m in re.finditer(r"\b([va])\[(\d+):(\d+)\]", t):
         base = 1000 if m.group(1) == "a" else 0
         regs.update(range(base + int(m.group(2)), base + int(m.group(3)) + 1))
     for m in re.finditer(r"\b([va])(\d+)\b", t):
         regs.add((1000 if m.group(1) == "a" else 0) + int(m.group(2)))
-    if in_asm and t.startswith("global_load"):
-        m = re.match(r"global_load_dword(?:x[234])? ([va])(?:\[(\d+):(\d+)\]|(\d+))", t)
-        base = 1000 if m.group(1) == "a" else 0
-        lo, hi = (int(m.group(2)), int(m.group(3))) if m.group(2) else (int(m.group(4)), int(m.group(4)))
-        dst = set(range(base + lo, base + hi + 1))
-        for r in dst:
-            if r in inflight:
-                print(f"line {ln}: load overwrites in-flight v{r} (loaded at line {inflight[r]})"); bad += 1
-        for r in dst:
-            inflight[r] = ln
-        continue
-    hit = regs & set(inflight)
-    if hit and not t.startswith("s_"):
-        print(f"line {ln}: `{t}` touches in-flight {sorted(hit)} (loaded at {sorted(set(inflight[r] for r in hit))})")
-        bad += 1
-print("asm prefetch check:", "OK" if not bad else f"{bad} violations")
-sys.exit(1 if bad else 0)
+    return regs
+
+
+def kernels(lines):
+    """(name, [(lineno, text, in_asm)]) per function body, up to its s_endpgm"""
+    out, cur, name, in_asm = [], None, None, False
+    for ln, text in enumerate(lines, 1):
+        t = text.strip()
+        m = re.match(r"^(_Z\w+):", text)
+        if m and cur is None:
+            name, cur = m.group(1), []
+            continue
+        if cur is None:
+            continue
+        if t.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if t.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        if t.startswith(".Lfunc_end"):
+            out.append((name, cur))
+            cur = None
+            continue
+        if not t or t.startswith(";") or (t.startswith(".") and not t.endswith(":")):
+            continue
+        cur.append((ln, t, in_asm))
+    return out
+
+
+def check(name, body):
+    # basic blocks
+    label_at, blocks, cur = {}, [], []
+    for item in body:
+        ln, t, _ = item
+        if t.endswith(":"):
+            if cur:
+                blocks.append(cur)
+                cur = []
+            label_at[t[:-1]] = len(blocks)
+            continue
+        cur.append(item)
+        if t.startswith(("s_branch", "s_cbranch", "s_endpgm", "s_setpc")):
+            blocks.append(cur)
+            cur = []
+    if cur:
+        blocks.append(cur)
+    succ = []
+    for i, b in enumerate(blocks):
+        last = b[-1][1] if b else ""
+        s = []
+        m = re.match(r"s_c?branch\w*\s+(\S+)", last)
+        if m and m.group(1) in label_at:
+            s.append(label_at[m.group(1)])
+        if not last.startswith(("s_branch", "s_endpgm", "s_setpc")) and i + 1 < len(blocks):
+            s.append(i + 1)
+        succ.append(s)
+    inflight_in = [dict() for _ in blocks]      # reg -> line of the load
+    reports = {}
+    work = [0] if blocks else []
+    seen_in = [None] * len(blocks)
+    while work:
+        i = work.pop()
+        state = dict(inflight_in[i])
+        for ln, t, in_asm in blocks[i]:
+            if in_asm and t.startswith("s_waitcnt vmcnt"):
+                state.clear()
+                continue
+            if t.startswith("s_endpgm"):
+                if state:
+                    reports[ln] = f"line {ln}: kernel ends with loads never waited for (loaded at {sorted(set(state.values()))})"
+                continue
+            m = LOAD.match(t) if in_asm else None
+            if m:
+                base = 1000 if m.group(1) == "a" else 0
+                lo, hi = (int(m.group(2)), int(m.group(3))) if m.group(2) else (int(m.group(4)), int(m.group(4)))
+                for r in range(base + lo, base + hi + 1):
+                    if r in state:
+                        reports[ln] = f"line {ln}: load overwrites in-flight v{r} (loaded at line {state[r]})"
+                    state[r] = ln
+                continue
+            if t.startswith("s_"):
+                continue
+            hit = regs_of(t) & set(state)
+            if hit:
+                reports[ln] = f"line {ln}: `{t}` touches in-flight {sorted(hit)} (loaded at {sorted(set(state[r] for r in hit))})"
+        for j in succ[i]:
+            merged = dict(inflight_in[j])
+            merged.update({r: l for r, l in state.items() if r not in merged})
+            if seen_in[j] is None or set(merged) != set(inflight_in[j]):
+                inflight_in[j] = merged
+                seen_in[j] = True
+                work.append(j)
+    return [reports[k] for k in sorted(reports)]
+
+
+def main():
+    lines = open(sys.argv[1]).read().splitlines()
+    bad = 0
+    for name, body in kernels(lines):
+        for r in check(name, body):
+            print(f"{name[:60]}: {r}")
+            bad += 1
+    print("asm prefetch check:", "OK" if not bad else f"{bad} violations")
+    sys.exit(1 if bad else 0)
+
+
+main()
