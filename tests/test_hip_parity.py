@@ -444,6 +444,24 @@ def test_overlapped_iterate_equals_plain_iterate(hip, R, C, top, bottom, dem32):
         assert a.run_block(5, 1e-6) == b.run_block(5, 1e-6)
 
 
+def test_overlapped_iterate_on_a_full_size_slab(hip):
+    """the 8-GPU slab of BASELINE config 4 (2079 x 16384): interior launch with DEM codes on two waves per
+    SIMD, boundary windows on the fp64 DEM - same bits as the single launch"""
+    R, C = 2079, 16384
+    dem = hip.synth_dem(C, C)[:R]
+    miss = -99999.0
+    bd, bw = pad(dem, np.full((R, C), 0.1), miss)
+    kw = dict(module="add", nrows=R, ncols=C, missingvalue=miss)
+    with hip.context(**kw) as a, hip.context(**kw) as b:
+        a.upload(bd, bw)
+        b.upload(bd, bw)
+        assert b.get_option(wdpm_amd.OPT_DEM32) == 1
+        for n in (4, 4):
+            a.iterate(n)
+            b.iterate_overlapped(n, 33, 44)
+            assert n_bit_diff(a.download_water(), b.download_water()) == 0
+
+
 def _volume_cases():
     from test_seqsum_model import cases
     return list(cases())
