@@ -25,8 +25,14 @@ def run(rank, world, port, libpath, case, outdir):
     if drain:
         dr, dc = find_drain(bd)
         kw.update(drainrow=dr, draincol=dc)
+    transport, fallback = HostTransport(dist), None
+    if case.get("failing_transport"):
+        class Refused:                       # a GPU-direct transport the platform refuses, on every rank
+            def exchange(self, ctx, sends, recvs):
+                raise RuntimeError("simulated: peer access refused")
+        transport, fallback = Refused(), HostTransport(dist)
     s = RowBlockSolver(lib, case["module"], case["R"], case["C"], miss, rank=rank, nranks=world,
-                       exchange_every=case["k"], transport=HostTransport(dist), dist=dist, **kw)
+                       exchange_every=case["k"], transport=transport, dist=dist, fallback_transport=fallback, **kw)
     s.upload_global(bd, bw)
     if drain:
         s.set_totaldrain(max(bw[dr, dc], 0.0))

@@ -122,6 +122,17 @@ def taint(rows, cols, k, bad):
     return t
 
 
+def test_refused_transport_falls_back_to_host_staging(oracle):
+    """bench.py hands RowBlockSolver a GPU-direct transport plus a host-staged one; if the first raises at
+    its first exchange (every rank sees the same refusal) the run continues on the second, same bits"""
+    case = dict(seed=23, R=150, C=70, module="add", k=2, thres=0.005 / 1000, blocks=[7], failing_transport=True)
+    want, mds = single(oracle, dict(case))
+    parts = run_ranks(2, case)
+    for p in parts:
+        assert bits_equal(p["own"], want[int(p["lo"]):int(p["hi"]) + 1])
+        assert list(p["mds"]) == mds
+
+
 def test_halo_depth_equals_worst_case_dependency_reach():
     """3k-1 rows above / 6k-2 below (slab boundaries = 2 mod 3, first slab row = 0 mod 3), and the
     fused kernel's per-iteration trapezoid: 8 columns left / 12 right, 2 rows up / 4 down"""
