@@ -1,14 +1,22 @@
 #!/usr/bin/env python3
 """bench.py — cell-updates/s of the WDPM Add module on a synthetic 16384 x 16384 DEM (BASELINE.json).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--size 16384]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size 16384] [--driver ranks|group]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One step = one iteration (all 9 colour passes) over the whole raster.  The timed region is one
 block of the reference's loop: threshold flush + snapshot, K iterations, max-|dw| reduction
 (src/WDPMCL.c:1055-1125,1239-1254), with the rasters already resident in HBM.  N > 1: row-block
-decomposition, one rank per GPU, halo refresh by RCCL send/recv (wdpm_amd/rowblock.py); total work
-is fixed, so scaling is strong.  Rank 0 prints ONE JSON line.
+decomposition, one rank per GPU, the C driver wdpm_amd/csrc/wdpm_rowblock.c on every rank, halo rows
+by RCCL send/recv issued by the library on its own stream; total work is fixed, so scaling is strong.
+Rank 0 prints ONE JSON line.
+
+`--gpus N` without a launcher (WORLD_SIZE unset) starts the N ranks itself, as child processes
+(`python -m torch.distributed.run ...` of this same file, before anything here has touched the GPU),
+relays rank 0's line and exits with the launcher's status.  `--driver group` instead runs all N ranks
+inside THIS process, one host thread per GPU (wdpm_group_*: what the WDPMCL drop-in does with
+WDPM_GPUS=N).  On a box with fewer GPUs than ranks (rehearsal) the ranks share GPUs, torch.distributed
+runs on gloo and the halos are staged through the host (RCCL wants one GPU per rank); the line says so.
 """
 import argparse
 import json
@@ -112,6 +120,27 @@ def cpu_baseline(n=4096, iters=32):
             "sample": f"oracle/wdpm_oracle.c, synthetic {n}x{n} all-wet add 100 mm, {iters} iterations, {dt:.1f} s"}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher: start the N ranks as CHILD processes (never exec: this
+    process has not touched the GPU and will not), relay rank 0's JSON line, return the launcher's status."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+    for ln in p.stdout.splitlines():
+        if not ln.startswith('{"metric"'):
+            print(ln, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    return p.returncode if p.returncode != 0 or lines else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -119,55 +148,49 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--size", type=int, default=16384)
     ap.add_argument("--exchange-every", type=int, default=int(os.environ.get("WDPM_EXCHANGE_EVERY", "4")))
-    ap.add_argument("--kernel", choices=["auto", "pass", "fused", "fused2", "fused2w"], default="auto")
+    ap.add_argument("--kernel", choices=["auto", "pass", "fused"], default="auto")
+    ap.add_argument("--driver", choices=["ranks", "group"], default="ranks",
+                    help="ranks = one process per GPU (torch.distributed.run); group = all ranks in this process, one "
+                         "host thread per GPU (what WDPMCL does with WDPM_GPUS=N)")
     ap.add_argument("--module", choices=["add", "drain"], default="add",
                     help="drain = BASELINE config 5: water-in is the add-100-mm state after --drain-spinup iterations")
     ap.add_argument("--drain-spinup", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    launched = "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not launched and args.driver == "ranks":
+        sys.exit(self_launch(args))
+
     import torch
     import wdpm_amd
-    from wdpm_amd.rowblock import DeviceTransport, RowBlockSolver
+    from wdpm_amd.rowblock import Group, HostTransport, RowBlockSolver
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N")
+    world = int(os.environ.get("WORLD_SIZE", "1")) if args.driver == "ranks" else 1
+    rank = int(os.environ.get("RANK", "0")) if args.driver == "ranks" else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if args.driver == "ranks" else 0
+    if args.driver == "ranks":
         args.gpus = world
-    if not torch.cuda.is_available():
-        sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    # rehearsal on a box with fewer GPUs than ranks: WDPM_DIST_BACKEND=gloo WDPM_HALO=host lets several
-    # ranks share one GPU (RCCL refuses that); the driver's real runs use nccl, one GPU per rank
-    backend = os.environ.get("WDPM_DIST_BACKEND", "nccl")
     ngpu = torch.cuda.device_count()
-    local_rank = local_rank % max(ngpu, 1)
-    torch.cuda.set_device(local_rank)
+    if ngpu < 1 or not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # fewer GPUs than ranks (rehearsal on a one-GPU box): ranks share GPUs, which RCCL refuses - gloo + host halos
+    shared = ngpu < args.gpus
+    backend = os.environ.get("WDPM_DIST_BACKEND", "gloo" if shared else "nccl")
+    halo = os.environ.get("WDPM_HALO", "host" if shared else "rccl")
+    device = local_rank % ngpu
+    torch.cuda.set_device(device)
     dist = None
     if world > 1:
         import torch.distributed as dist
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     lib = wdpm_amd.load_hip()
     n = args.size
-    kernel = {"auto": wdpm_amd.KERNEL_AUTO, "pass": wdpm_amd.KERNEL_PASS, "fused": wdpm_amd.KERNEL_FUSED,
-              "fused2": wdpm_amd.KERNEL_FUSED2, "fused2w": wdpm_amd.KERNEL_FUSED2W}[args.kernel]
-    transport = fallback = None
-    if world > 1:
-        from wdpm_amd.rowblock import HostTransport
-        if backend == "nccl":
-            # GPU-direct halos over RCCL; a host-staged gloo path stands by should the platform refuse them
-            host = HostTransport(dist, dist.new_group(backend="gloo"))
-            transport, fallback = DeviceTransport(dist, torch.device("cuda", local_rank)), host
-            if os.environ.get("WDPM_HALO", "device") == "host":
-                transport, fallback = host, None
-        else:
-            transport = HostTransport(dist, None)
+    kernel = {"auto": wdpm_amd.KERNEL_AUTO, "pass": wdpm_amd.KERNEL_PASS, "fused": wdpm_amd.KERNEL_FUSED}[args.kernel]
     drain_kw = {}
     if args.module == "drain":
         # the outlet is the first row-major minimum of the DEM (WDPMCL.c:1005-1017), padded coordinates
@@ -175,34 +198,13 @@ def main():
         k = int(np.argmin(full))
         drain_kw = dict(drainrow=k // n + 1, draincol=k % n + 1)
         del full
-    solver = RowBlockSolver(lib, "add", n, n, MISSING, rank=rank, nranks=world, exchange_every=args.exchange_every,
-                            transport=transport, dist=dist, device=local_rank, kernel=kernel,
-                            fallback_transport=fallback)
-    solver.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    bd, bw = build_slab_inputs(lib, n, solver.slab)
-    solver.ctx.upload(bd, bw)
-    solver.agree_on_options()
-    if args.module == "drain":
-        # spin the water up with the add module, then hand the state to a drain solver
-        solver.run_block(args.drain_spinup, THRES)
-        solver.exchange()
-        bw = solver.ctx.download_water()
-        solver.close()
-        solver = RowBlockSolver(lib, "drain", n, n, MISSING, rank=rank, nranks=world,
-                                exchange_every=args.exchange_every, transport=solver.transport, dist=dist,
-                                device=local_rank, kernel=kernel, **drain_kw)
-        solver.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-        solver.ctx.upload(bd, bw)
-        solver.agree_on_options()
-        s = solver.slab
-        dr = drain_kw["drainrow"]
-        w_out = float(bw[dr - s.row0, drain_kw["draincol"]]) if s.row0 <= dr < s.row0 + s.rows else 0.0
-        if world > 1:
-            t = torch.tensor([w_out], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            w_out = float(t.item())
-        solver.set_totaldrain(max(w_out, 0.0))
-    del bd, bw
+
+    def dist_max(v):
+        if world == 1:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     def sync():
         torch.cuda.synchronize()
@@ -210,62 +212,148 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    solver.run_block(args.warmup, THRES)           # untimed warm-up steps
-    if world > 1:
-        solver.exchange()                          # the transport's first use (communicator set-up) is never timed
-    sync()
-    solver.ctx.timing_reset()
-    t0 = time.perf_counter()
-    max_diff = solver.run_block(args.steps, THRES) # exactly K timed steps
+    def whole_inputs():
+        dem = lib.synth_dem(n, n)
+        bd = np.full((n + 2, n + 2), MISSING)
+        bd[1:-1, 1:-1] = dem
+        del dem
+        return bd, np.where(bd > MISSING, ADD_M, 0.0)
+
     stats_s = None
-    if args.module == "drain":
-        # the drain module's per-block bookkeeping (WDPMCL.c:1257-1268) belongs to the block loop: |d totaldrain|
-        # and the sequential row-major volume sum (host, streamed down in chunks; rank-chained at N > 1)
+    rccl_ranks = None
+    if args.driver == "group":
+        # ---- all ranks in this process: wdpm_group_* (thread per GPU, RCCL via ncclCommInitAll or peer copies)
+        devs = [int(d) for d in os.environ["WDPM_DEVICES"].split(",")] if os.environ.get("WDPM_DEVICES") else \
+               [g % ngpu for g in range(args.gpus)]
+        bd, bw = whole_inputs()
+        grp = Group(lib, "add", n, n, MISSING, devs, exchange_every=args.exchange_every, kernel=kernel)
+        grp.upload(bd, bw)
+        if args.module == "drain":
+            grp.run_block(args.drain_spinup, THRES)
+            bw = grp.download_water()
+            grp.close()
+            grp = Group(lib, "drain", n, n, MISSING, devs, exchange_every=args.exchange_every, kernel=kernel, **drain_kw)
+            grp.upload(bd, bw)
+            grp.set_totaldrain(max(float(bw[drain_kw["drainrow"], drain_kw["draincol"]]), 0.0))
+        del bd, bw
+        ranks_used, halo = grp.size, wdpm_amd.HALO_NAMES[grp.halo_kind]
+        ctx0 = grp.rank_ctx(0)
+        grp.run_block(args.warmup, THRES)           # untimed warm-up steps (ends with a synchronous reduction)
+        e0, _ = grp.enqueue_stats()
+        lib.check(lib.dll.wdpm_timing_reset(ctx0))
+        t0 = time.perf_counter()
+        max_diff = grp.run_block(args.steps, THRES)  # exactly K timed steps
+        if args.module == "drain":
+            ts = time.perf_counter()
+            grp.drain_stats()
+            stats_s = time.perf_counter() - ts
         torch.cuda.synchronize()
-        ts = time.perf_counter()
-        solver.drain_stats()
-        stats_s = time.perf_counter() - ts
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    launches, kernel_ms = solver.ctx.timing()
-    dem32 = bool(solver.ctx.get_option(wdpm_amd.OPT_DEM32)) and args.module == "add"
+        dt = time.perf_counter() - t0
+        e1, _ = grp.enqueue_stats()
+        enqueue_us = (e1 - e0) / max(ranks_used, 1) / max(args.steps, 1) * 1e6
+        import ctypes as C
+        la, ms = C.c_int64(), C.c_double()
+        lib.check(lib.dll.wdpm_timing_get(ctx0, C.byref(la), C.byref(ms)))
+        launches, kernel_ms = la.value, ms.value
+        v = C.c_int64()
+        lib.check(lib.dll.wdpm_get_option(ctx0, wdpm_amd.OPT_DEM32, C.byref(v)))
+        dem32 = bool(v.value) and args.module == "add"
+        sl = wdpm_amd.capi.SlabStruct()
+        lib.check(lib.dll.wdpm_rank_slab(lib.dll.wdpm_group_rank(grp._h, 0), 0, C.byref(sl)))
+        own_rows0 = sl.own_hi - sl.own_lo + 1 if ranks_used > 1 else n
+        decomposition = f"row-block x{ranks_used}, one process, one host thread per GPU" if ranks_used > 1 else "single GPU"
+        closer = grp.close
+    else:
+        # ---- one process per GPU: wdpm_rank_* with RCCL halos (or host-staged ones when ranks share a GPU)
+        transport = HostTransport(dist) if world > 1 and halo == "host" else None
+        mk = dict(rank=rank, nranks=world, exchange_every=args.exchange_every, transport=transport, dist=dist,
+                  device=device, kernel=kernel, halo=halo if world > 1 else None)
+        solver = RowBlockSolver(lib, "add", n, n, MISSING, **mk)
+        bd, bw = build_slab_inputs(lib, n, solver.slab)
+        solver.upload(bd, bw)
+        if args.module == "drain":
+            # spin the water up with the add module, then hand the state to a drain solver
+            solver.run_block(args.drain_spinup, THRES)
+            solver.exchange()
+            bw = solver.ctx.download_water()
+            solver.close()
+            solver = RowBlockSolver(lib, "drain", n, n, MISSING, **mk, **drain_kw)
+            s = solver.slab
+            if s.rows != bd.shape[0]:
+                # the drain partition keeps the outlet three rows clear of every boundary and moved one: the add
+                # run's slabs no longer fit (the synthetic DEMs drain at a corner, so this does not happen there)
+                sys.exit("bench.py: the drain partition differs from the add run's; use --driver group")
+            solver.upload(bd, bw)
+            dr = drain_kw["drainrow"]
+            w_out = float(bw[dr - s.row0, drain_kw["draincol"]]) if s.row0 <= dr < s.row0 + s.rows else 0.0
+            solver.set_totaldrain(max(dist_max(w_out), 0.0))
+        del bd, bw
+        ranks_used = world
+        rccl_ranks = solver.rccl_ranks()
+        solver.run_block(args.warmup, THRES)           # untimed warm-up steps
+        if world > 1:
+            solver.exchange()                          # the transport's first use is never timed
+        sync()
+        solver.ctx.timing_reset()
+        t0 = time.perf_counter()
+        max_diff = solver.run_block(args.steps, THRES) # exactly K timed steps
+        if args.module == "drain":
+            # the drain module's per-block bookkeeping (WDPMCL.c:1257-1268) belongs to the block loop: |d totaldrain|
+            # and the sequential row-major volume sum (evaluated exactly on the device; rank-chained at N > 1)
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            solver.drain_stats()
+            stats_s = time.perf_counter() - ts
+        sync()
+        dt = dist_max(time.perf_counter() - t0)
+        launches, kernel_ms = solver.ctx.timing()
+        dem32 = bool(solver.ctx.get_option(wdpm_amd.OPT_DEM32)) and args.module == "add"
+        own_rows0 = solver.slab.own_hi - solver.slab.own_lo + 1 if world > 1 else n
+        decomposition = f"row-block x{world}, one process per GPU" if world > 1 else "single GPU"
+        enqueue_us = None
+        closer = solver.close
 
     if rank == 0:
         cells = float(n) * n
         value = cells * args.steps / dt
-        own_cells = float(solver.slab.own_hi - solver.slab.own_lo + 1) * n if world > 1 else cells
-        iter_ms = kernel_ms / max(args.steps, 1)     # device time of one iteration's stencil launch(es)
+        own_cells = float(own_rows0) * n                 # rank 0's share: what its kernel launches process
+        iter_ms = kernel_ms / max(args.steps, 1)         # device time of one iteration's stencil launch(es), rank 0
         achieved = ALGO_BYTES_PER_CELL_UPDATE * own_cells / (iter_ms * 1e-3) / 1e9 if iter_ms > 0 else 0.0
+        moved = (20.0 if dem32 else 24.0) * own_cells    # what the kernel really streams (DEM as 4-byte codes or fp64)
+        traffic = measured_traffic(n, ranks_used, args.kernel, dem32)
         out = {
-            "metric": "cell-updates/sec on Add module, 16k x 16k DEM" if args.module == "add" else
-                      "cell-updates/sec on Drain module (BASELINE config 5)",
-            "value": value, "unit": "cell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": (f"cell-updates/sec on Add module, {n}x{n} DEM" if args.module == "add" else
+                       f"cell-updates/sec on Drain module, {n}x{n} DEM (BASELINE config 5)"),
+            "value": value, "unit": "cell-updates/s", "n_gpus": ranks_used, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": (f"synthetic {n}x{n} diamond-square DEM (seed {n}), Add 100 mm, rof 1.0, "
                                     f"thres 0.005 mm, one block of {args.steps} iterations") if args.module == "add" else
                                    (f"synthetic {n}x{n} DEM (seed {n}), Drain from the add-100-mm state after "
                                     f"{args.drain_spinup} iterations, one block of {args.steps} iterations"),
-                       "kernel": args.kernel, "decomposition": f"row-block x{world}" if world > 1 else "single GPU",
-                       "exchange_every": args.exchange_every if world > 1 else None,
+                       "kernel": args.kernel, "driver": args.driver, "decomposition": decomposition,
+                       "exchange_every": args.exchange_every if ranks_used > 1 else None,
+                       "halo": halo if ranks_used > 1 else None, "rccl_ranks": rccl_ranks,
+                       "dist_backend": backend if world > 1 else None,
                        "max_diff_m": max_diff,
+                       **({"enqueue_us_per_iteration_per_rank": enqueue_us} if enqueue_us is not None else {}),
                        **({"drain_bookkeeping_ms_per_block": stats_s * 1e3} if stats_s is not None else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n, world, args.kernel, dem32),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": "profiles/traffic.json (rocprofv3 --pmc passes of this command, committed)"
+                                           if traffic is not None else None,
                          "dem": "32-bit codes, verified lossless on upload (20 B of HBM traffic per cell-update)" if dem32
                                 else "fp64 (24 B of HBM traffic per cell-update)",
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_CELL_UPDATE * own_cells,
+                         "moved_bytes_per_launch": moved,
+                         "moved_frac": moved / (iter_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if iter_ms > 0 else 0.0,
                          "kernel_ms_per_iteration": iter_ms, "launches": launches,
-                         "job_frac": value * ALGO_BYTES_PER_CELL_UPDATE / 1e9 / (HBM_PEAK_GBS * world)},
+                         "job_frac": value * ALGO_BYTES_PER_CELL_UPDATE / 1e9 / (HBM_PEAK_GBS * ranks_used)},
         }
-        if not args.no_cpu_baseline and world == 1:   # rank 0 at N=1 only
+        if not args.no_cpu_baseline and ranks_used == 1:   # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    solver.close()
+    closer()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -69,7 +69,8 @@ typedef struct wdpm_params {
  * clCreateBuffer/clReleaseMemObject churn (WDPMCL.c:1138-1141,1223-1227): buffers persist. */
 int  wdpm_create(wdpm_ctx **out, const wdpm_params *p);
 void wdpm_destroy(wdpm_ctx *ctx);                      /* WDPMCL.c:1475-1483 */
-const char *wdpm_last_error(void);                     /* replaces exitOnFail(), WDPMCL.c:225-232 */
+const char *wdpm_last_error(void);                     /* replaces exitOnFail(), WDPMCL.c:225-232; per host thread */
+void wdpm_set_last_error(const char *msg);             /* drivers above the ABI hand a worker thread's message to the caller's */
 const char *wdpm_backend_name(void);                   /* "hip-gfx950" or "oracle-cpu" */
 int  wdpm_abi_version(void);
 
@@ -141,29 +142,115 @@ int wdpm_timing_get(wdpm_ctx *ctx, int64_t *launches, double *ms);
 
 /* copy `nrows` rows of the CURRENT water raster from slab-local row `src_row` of `src` to row
  * `dst_row` of `dst` (same raster width).  Device to device on the HIP back-end (peer copy over
- * xGMI when the contexts live on different GPUs), ordered after everything queued on either
- * context and before anything queued on either afterwards — on the devices (stream events); the
- * call does not wait for the copy.  This is the halo refresh primitive of single-process
- * multi-GPU runs (wdpm_group_*). */
+ * xGMI when the contexts live on different GPUs; direct peer access is enabled on first use),
+ * ordered after everything queued on either context and before anything queued on either
+ * afterwards — on the devices (stream events); the call does not wait for the copy.  The halo
+ * refresh primitive of the in-process peer-copy transport (WDPM_HALO_PEER).  One host thread at a
+ * time may use a given context. */
 int wdpm_copy_rows(wdpm_ctx *dst, int32_t dst_row, wdpm_ctx *src, int32_t src_row, int32_t nrows);
+/* hipDeviceCanAccessPeer / hipDeviceEnablePeerAccess in both directions between the contexts' devices
+ * (a refusal is reported on stderr and leaves staged copies in charge; the CPU restatement: no-op) */
+int wdpm_enable_peer_access(wdpm_ctx *a, wdpm_ctx *b);
 
-/* -- a raster spread over several GPUs of one process (what WDPMCL uses when WDPM_GPUS > 1) ------
- * Row-block decomposition: device g owns padded rows [L_g, H_g] (L_g % 3 == 2) and holds 3k-1
- * halo rows above / 6k-2 below, runs k = exchange_every iterations without communication, then
- * refreshes the halos from its neighbours' owned rows with wdpm_copy_rows.  Results are
- * bit-identical to a single context.  `p` describes the WHOLE raster (slab/device fields ignored);
- * devices[] may name the same device several times (testing on one GPU). */
+/* -- RCCL halos (product library; the CPU restatement has none and fails these calls) ------------
+ * Replaces the reference's device set-up, which picks ONE OpenCL device (create_device(),
+ * WDPMCL.c:80-121, :598-638): a context joins an RCCL communicator, one rank per GPU. */
+#define WDPM_COMM_ID_BYTES 128
+typedef struct wdpm_halo_op { int32_t peer, row, nrows; } wdpm_halo_op;   /* rank, slab-local first row, row count */
+int wdpm_comm_available(void);                         /* 1 when the RCCL library could be bound */
+const char *wdpm_comm_version(void);
+int wdpm_comm_unique_id(void *id128);                  /* ncclGetUniqueId: rank 0 makes it, every rank gets a copy */
+/* one process per rank: collective over all ranks (ncclCommInitRank on the context's device) */
+int wdpm_comm_init_rank(wdpm_ctx *ctx, int32_t nranks, int32_t rank, const void *id128);
+/* all ranks in one process: ncclCommInitAll over the contexts' (distinct) devices, rank = index */
+int wdpm_comm_init_all(wdpm_ctx **ctxs, int32_t n);
+int wdpm_comm_size(wdpm_ctx *ctx, int32_t *nranks, int32_t *rank);   /* as RCCL reports it (ncclCommCount) */
+/* grouped ncclSend / ncclRecv of rows of the CURRENT water raster on the context's stream; returns
+ * once queued.  Every rank must call it with matching ops. */
+int wdpm_comm_exchange(wdpm_ctx *ctx, int32_t nsend, const wdpm_halo_op *sends, int32_t nrecv, const wdpm_halo_op *recvs);
+/* all[r*n + i] = mine[i] of rank r on every rank (n <= 8); synchronous */
+int wdpm_comm_allgather(wdpm_ctx *ctx, const double *mine, int32_t n, double *all);
+
+/* -- row-block decomposition: the raster over several GPUs (wdpm_rowblock.c, both libraries) ------
+ * New work relative to the single-device reference.  Rank g owns padded rows
+ * [own_lo, own_hi] (own_lo % 3 == 2) and holds 3k-1 halo rows above / 6k-2 below, runs
+ * k = exchange_every iterations without communication, then refreshes the halos from its
+ * neighbours' owned rows; the last iteration before a refresh is split so that the transfer
+ * overlaps its interior rows (wdpm_iterate_overlapped).  Results are bit-identical to one context.
+ * For the drain module the partition keeps the outlet's row at least three rows inside its owner's
+ * rows, so that everything totaldrain is summed from is exact in the owner. */
+typedef struct wdpm_slab {
+  int32_t own_lo, own_hi;   /* owned padded rows of the whole raster, inclusive */
+  int32_t row0, rows;       /* slab held: first padded row (multiple of 3), row count */
+  int32_t up, down;         /* halo rows held above own_lo / below own_hi */
+} wdpm_slab;
+/* slabs[0..nranks): 0 on success, 1 when some slab would be shorter than the halo it must serve.
+ * drainrow < 0 (or a module other than WDPM_DRAIN): no outlet to keep clear of. */
+int wdpm_partition(int32_t nrows, int32_t nranks, int32_t exchange_every, int32_t module, int32_t drainrow,
+                   wdpm_slab *slabs);
+
+/* how halo rows travel between ranks */
+enum {
+  WDPM_HALO_AUTO = 0,   /* RCCL where it can be had, else the next that applies */
+  WDPM_HALO_RCCL = 1,   /* ncclSend/ncclRecv on the context's stream (wdpm_comm_*) */
+  WDPM_HALO_PEER = 2,   /* ranks of ONE process: hipMemcpyPeerAsync between the contexts (wdpm_copy_rows) */
+  WDPM_HALO_HOST = 3    /* staged through host memory and moved by the caller's functions (e.g. gloo): several
+                           ranks sharing one GPU in tests, or a platform that refuses the device paths */
+};
+/* WDPM_HALO_HOST: the caller moves the bytes.  Both functions are collective and return 0 on success. */
+typedef struct wdpm_host_transport {
+  void *user;
+  /* n_ops buffers: is_send[i] ? send count[i] doubles at buf[i] to rank peer[i] : receive them from it */
+  int (*exchange)(void *user, int32_t n_ops, const int32_t *is_send, const int32_t *peer, double *const *buf,
+                  const int64_t *count);
+  /* all[r*n + i] = mine[i] of rank r */
+  int (*allgather)(void *user, const double *mine, int32_t n, double *all);
+} wdpm_host_transport;
+
+/* One rank of a decomposed run: its slab context plus its end of the halo transport.  Every function
+ * marked (collective) must be called by all ranks.  `whole` describes the whole raster; its device field
+ * names this rank's GPU.  rccl_id: WDPM_COMM_ID_BYTES from wdpm_comm_unique_id of rank 0 (RCCL), host: the
+ * caller's transport (HOST); AUTO takes RCCL when rccl_id is given, else HOST. */
+typedef struct wdpm_rank wdpm_rank;
+int  wdpm_rank_create(wdpm_rank **out, const wdpm_params *whole, int32_t rank, int32_t nranks, int32_t exchange_every,
+                      int32_t halo, const void *rccl_id, const wdpm_host_transport *host);   /* (collective) */
+void wdpm_rank_destroy(wdpm_rank *r);
+wdpm_ctx *wdpm_rank_ctx(wdpm_rank *r);                                   /* the slab context (timing, options, rows) */
+int  wdpm_rank_slab(wdpm_rank *r, int32_t of_rank, wdpm_slab *out);      /* of_rank < 0: this rank's */
+int  wdpm_rank_info(wdpm_rank *r, int32_t *halo, int32_t *exchange_every, int32_t *drain_owner);
+int  wdpm_rank_upload(wdpm_rank *r, const double *slab_dem, const double *slab_water);      /* (collective) this rank's slab rows */
+int  wdpm_rank_upload_global(wdpm_rank *r, const double *bigdem, const double *bigwater);   /* (collective) whole padded rasters */
+int  wdpm_rank_set_totaldrain(wdpm_rank *r, double v);
+int  wdpm_rank_get_totaldrain(wdpm_rank *r, double *v);                  /* (collective) the outlet owner's value */
+int  wdpm_rank_begin_block(wdpm_rank *r, double thres);
+int  wdpm_rank_iterate(wdpm_rank *r, int32_t n_iter);                    /* (collective) halo refresh every k iterations */
+int  wdpm_rank_exchange(wdpm_rank *r);                                   /* (collective) refresh the halos now */
+int  wdpm_rank_max_diff(wdpm_rank *r, double *max_diff);                 /* (collective) over all ranks' owned rows */
+int  wdpm_rank_run_block(wdpm_rank *r, int32_t n_iter, double thres, double *max_diff);     /* (collective) */
+int  wdpm_rank_drain_stats(wdpm_rank *r, double *diffdrain, double *final_sum);             /* (collective) */
+int  wdpm_rank_download_owned(wdpm_rank *r, double *dst);                /* own_hi-own_lo+1 rows */
+
+/* -- a raster spread over several GPUs of ONE process (what WDPMCL uses when WDPM_GPUS > 1) ------
+ * The same ranks, each driven by its own host thread; halos by RCCL (ncclCommInitAll) when the
+ * devices are distinct and RCCL can be bound, else by peer copies (WDPM_HALO=rccl|peer in the
+ * environment decides otherwise).  `p` describes the WHOLE raster (slab/device fields ignored);
+ * devices[] may name the same device several times (testing on one GPU: peer-copy transport). */
 typedef struct wdpm_group wdpm_group;
 int  wdpm_group_create(wdpm_group **out, const wdpm_params *p, int32_t ndev, const int32_t *devices,
                        int32_t exchange_every);
 void wdpm_group_destroy(wdpm_group *grp);
 int  wdpm_group_size(wdpm_group *grp);                      /* devices actually used */
+int  wdpm_group_halo(wdpm_group *grp);                      /* WDPM_HALO_* in use (0 for one device) */
+wdpm_rank *wdpm_group_rank(wdpm_group *grp, int32_t i);
 int  wdpm_group_upload(wdpm_group *grp, const double *bigdem, const double *bigwater);
 int  wdpm_group_download_water(wdpm_group *grp, double *bigwater);
 int  wdpm_group_set_totaldrain(wdpm_group *grp, double v);
 int  wdpm_group_get_totaldrain(wdpm_group *grp, double *v);
 int  wdpm_group_run_block(wdpm_group *grp, int32_t n_iter, double thres, double *max_diff);
 int  wdpm_group_drain_stats(wdpm_group *grp, double *diffdrain, double *final_sum);
+/* host time the group's threads spent queueing work in wdpm_group_run_block since creation (summed over
+ * ranks, seconds) and the iterations ONE rank queued: enqueue cost per iteration and rank */
+int  wdpm_group_enqueue_stats(wdpm_group *grp, double *seconds, int64_t *iterations);
 
 /* -- options -----------------------------------------------------------------------------------
  * WDPM_OPT_SIGNED_ZERO_SAFE (get/set): 1 = the add/subtract stencil must preserve the sign of

@@ -25,18 +25,29 @@ def run(rank, world, port, libpath, case, outdir):
     if drain:
         dr, dc = find_drain(bd)
         kw.update(drainrow=dr, draincol=dc)
-    transport, fallback = HostTransport(dist), None
+    transport = HostTransport(dist)
     if case.get("failing_transport"):
-        class Refused:                       # a GPU-direct transport the platform refuses, on every rank
-            def exchange(self, ctx, sends, recvs):
-                raise RuntimeError("simulated: peer access refused")
-        transport, fallback = Refused(), HostTransport(dist)
+        class Refusing(HostTransport):       # the caller's transport raises: the error must surface, not hang
+            def _exchange_cb(self, *a):
+                self.error = RuntimeError("simulated: transport refused")
+                return 1
+        transport = Refusing(dist)
     s = RowBlockSolver(lib, case["module"], case["R"], case["C"], miss, rank=rank, nranks=world,
-                       exchange_every=case["k"], transport=transport, dist=dist, fallback_transport=fallback, **kw)
+                       exchange_every=case["k"], transport=transport, dist=dist, **kw)
     s.upload_global(bd, bw)
     if drain:
         s.set_totaldrain(max(bw[dr, dc], 0.0))
     mds, stats = [], []
+    if case.get("failing_transport"):
+        try:
+            s.run_block(case["blocks"][0], case["thres"])
+        except RuntimeError as e:
+            assert "simulated" in str(e)
+            np.savez(os.path.join(outdir, f"rank{rank}.npz"), refused=1)
+            s.close()
+            dist.destroy_process_group()
+            return
+        raise SystemExit("the refused transport went unnoticed")
     for n in case["blocks"]:
         mds.append(s.run_block(n, case["thres"]))
         if drain:

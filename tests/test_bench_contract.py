@@ -24,7 +24,7 @@ def run_bench(*args):
 
 def test_bench_line_has_the_contract_fields():
     d = run_bench("--size", "1024", "--steps", "7", "--warmup", "2")
-    assert d["metric"].startswith("cell-updates/sec on Add module") and d["unit"] == "cell-updates/s"
+    assert d["metric"] == "cell-updates/sec on Add module, 1024x1024 DEM" and d["unit"] == "cell-updates/s"
     assert d["n_gpus"] == 1 and d["steps"] == 7 and d["warmup"] == 2
     assert d["higher_is_better"] is True and d["scaling"] == "strong" and d["vs_baseline"] is None
     assert d["dtype"] == "f64" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
@@ -42,3 +42,24 @@ def test_bench_drain_line():
     d = run_bench("--module", "drain", "--size", "1024", "--steps", "5", "--warmup", "1", "--drain-spinup", "20",
                   "--no-cpu-baseline")
     assert d["metric"].startswith("cell-updates/sec on Drain module") and d["value"] > 0 and "cpu_baseline" not in d
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher: the ranks are child processes of bench.py (one GPU here, so
+    they share it: gloo + host-staged halos - the driver's multi-GPU boxes get nccl + RCCL halos), ONE line out"""
+    d = run_bench("--gpus", "2", "--size", "1536", "--steps", "12", "--warmup", "3", "--exchange-every", "2")
+    assert d["n_gpus"] == 2 and d["steps"] == 12 and d["value"] > 0
+    c = d["config"]
+    assert c["driver"] == "ranks" and c["halo"] == "host" and c["dist_backend"] == "gloo" and c["rccl_ranks"] is None
+    assert "cpu_baseline" not in d
+    one = run_bench("--size", "1536", "--steps", "12", "--warmup", "3", "--no-cpu-baseline")
+    assert one["config"]["max_diff_m"] == c["max_diff_m"]          # same block, same bits
+
+
+def test_bench_group_driver():
+    """--driver group: all ranks inside bench.py's process, one host thread per slab (what WDPMCL does)"""
+    d = run_bench("--gpus", "3", "--driver", "group", "--size", "1536", "--steps", "12", "--warmup", "3",
+                  "--exchange-every", "3")
+    c = d["config"]
+    assert d["n_gpus"] == 3 and c["driver"] == "group" and c["halo"] == "peer"
+    assert c["enqueue_us_per_iteration_per_rank"] > 0

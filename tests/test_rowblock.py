@@ -13,7 +13,7 @@ import pytest
 
 from conftest import ORACLE_SO, ROOT
 from helpers import bits_equal, find_drain, n_bit_diff, pad, random_case
-from wdpm_amd.rowblock import RowBlockSolver, halo_depth, partition
+from wdpm_amd.rowblock import Group, RowBlockSolver, halo_depth, partition
 
 
 def free_port():
@@ -55,9 +55,9 @@ def single(oracle, case):
     return w, mds
 
 
-def test_partition_properties():
+def test_partition_properties(oracle):
     for nrows, n, k in [(16384, 8, 4), (16384, 8, 1), (16384, 2, 10), (482, 3, 2), (8192, 4, 16), (100, 2, 1)]:
-        slabs = partition(nrows, n, k)
+        slabs = partition(oracle, nrows, n, k)
         up, down = halo_depth(k)
         assert slabs[0].own_lo == 0 and slabs[-1].own_hi == nrows + 1
         for a, b in zip(slabs, slabs[1:]):
@@ -71,7 +71,24 @@ def test_partition_properties():
             if s.rank < n - 1:
                 assert s.down == min(down, nrows + 1 - s.own_hi)
     with pytest.raises(ValueError):
-        partition(60, 4, 8)
+        partition(oracle, 60, 4, 8)
+
+
+def test_partition_keeps_the_outlet_inside_its_owner(oracle):
+    """drain: totaldrain is summed from rows dr-1 .. dr+1, which must be OWNED rows of the rank that
+    reports it (a halo row is stale by the k-th iteration after a refresh): every boundary stays
+    at least three rows away from the outlet's row, and stays = 2 (mod 3)"""
+    for nrows, n, k in [(150, 2, 1), (150, 2, 3), (400, 3, 2), (8192, 8, 4)]:
+        plain = partition(oracle, nrows, n, k)
+        for b in [s.own_lo for s in plain[1:]]:
+            for dr in range(max(1, b - 5), min(nrows, b + 5) + 1):
+                slabs = partition(oracle, nrows, n, k, "drain", dr)
+                owner = [s for s in slabs if s.own_lo <= dr <= s.own_hi]
+                assert len(owner) == 1
+                o = owner[0]
+                assert (o.rank == 0 or dr - o.own_lo >= 3) and (o.rank == n - 1 or o.own_hi - dr >= 3), (nrows, n, k, dr, o)
+                for a, c in zip(slabs, slabs[1:]):
+                    assert c.own_lo == a.own_hi + 1 and c.own_lo % 3 == 2 and c.row0 % 3 == 0
 
 
 @pytest.mark.parametrize("world,k", [(2, 1), (2, 4), (3, 2)])
@@ -122,15 +139,64 @@ def taint(rows, cols, k, bad):
     return t
 
 
-def test_refused_transport_falls_back_to_host_staging(oracle):
-    """bench.py hands RowBlockSolver a GPU-direct transport plus a host-staged one; if the first raises at
-    its first exchange (every rank sees the same refusal) the run continues on the second, same bits"""
+def test_a_refused_transport_surfaces_on_every_rank(oracle):
+    """the caller's host transport failing (every rank sees the refusal at the first exchange) comes back
+    through the C driver as the caller's own exception - no hang, no silent continuation on stale halos"""
     case = dict(seed=23, R=150, C=70, module="add", k=2, thres=0.005 / 1000, blocks=[7], failing_transport=True)
-    want, mds = single(oracle, dict(case))
     parts = run_ranks(2, case)
-    for p in parts:
-        assert bits_equal(p["own"], want[int(p["lo"]):int(p["hi"]) + 1])
-        assert list(p["mds"]) == mds
+    assert all(int(p["refused"]) == 1 for p in parts)
+
+
+def group_run(lib, case, devices, dr=None, dc=None):
+    """the ranks of ONE process (wdpm_group_*: one host thread per slab) on `devices`"""
+    dem, water, miss = random_case(case["seed"], case["R"], case["C"], **case.get("gen", {}))
+    bd, bw = pad(dem, water, miss)
+    kw = {}
+    if case["module"] == "drain":
+        if dr is None:
+            dr, dc = find_drain(bd)
+        kw = dict(drainrow=dr, draincol=dc)
+    with Group(lib, case["module"], case["R"], case["C"], miss, devices, exchange_every=case["k"], **kw) as g:
+        g.upload(bd, bw)
+        if kw:
+            g.set_totaldrain(max(bw[dr, dc], 0.0))
+        mds, stats = [], []
+        for n in case["blocks"]:
+            mds.append(g.run_block(n, case["thres"]))
+            if kw:
+                stats.append(list(g.drain_stats()) + [g.totaldrain()])
+        return g.download_water(), mds, stats, g.size
+
+
+@pytest.mark.parametrize("n,k", [(2, 1), (3, 2), (4, 1)])
+def test_thread_per_rank_group_equals_single_context(oracle, n, k):
+    """wdpm_group: the same C ranks driven by one host thread each inside one process"""
+    case = dict(seed=31, R=260, C=50, module="add", k=k, thres=0.005 / 1000, blocks=[11, 6])
+    want, mds, _, _ = group_run(oracle, case, [0])
+    got, mds_n, _, size = group_run(oracle, case, [0] * n)
+    assert size == n and bits_equal(got, want) and mds_n == mds
+
+
+@pytest.mark.parametrize("where", ["own_lo", "own_lo+1", "own_hi-1", "own_hi", "own_lo-1"])
+@pytest.mark.parametrize("k", [1, 2, 3])
+def test_drain_outlet_next_to_a_slab_boundary(oracle, where, k):
+    """with the outlet on the first owned row of a slab, row dr-1 was a halo row and totaldrain
+    went wrong by the k-th iteration after a refresh.  The outlet is forced onto the rows around the
+    boundary an outlet-blind partition would choose; water, totaldrain, |d totaldrain| and the volume sum
+    must all equal the single-context values"""
+    R, C = 150, 40
+    case = dict(seed=41, R=R, C=C, module="drain", k=k, thres=0.005 / 1000, blocks=[3 * k + 1, 2 * k],
+                gen=dict(missing_frac=0.0, dry_frac=0.1))
+    plain = partition(oracle, R, 2, k)
+    b = plain[1].own_lo
+    dr = {"own_lo": b, "own_lo+1": b + 1, "own_hi-1": b - 2, "own_hi": b - 1, "own_lo-1": b - 1}[where]
+    dc = 17
+    want, mds, stats, _ = group_run(oracle, case, [0], dr, dc)
+    got, mds2, stats2, size = group_run(oracle, case, [0, 0], dr, dc)
+    assert size == 2
+    assert bits_equal(got, want) and mds2 == mds
+    assert stats2 == stats, (stats2, stats)
+    assert stats[0][2] > 0
 
 
 def test_halo_depth_equals_worst_case_dependency_reach():
@@ -222,3 +288,28 @@ def test_multirank_hip_drain_over_gloo(oracle, hip):
         assert bits_equal(g["own"], want[lo:hi + 1])
         assert list(g["mds"]) == mds
         assert g["stats"].tolist() == stats
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("module,n,k", [("add", 3, 3), ("add", 4, 1), ("drain", 2, 2), ("drain", 3, 1)])
+def test_hip_group_threads_equal_single_context(oracle, hip, module, n, k):
+    """wdpm_group on the HIP back-end: n slabs of one GPU, one host thread each, peer-copy halos chained by
+    stream events, the overlapped last iteration before every refresh - against the oracle on one slab"""
+    case = dict(seed=33, R=300, C=420, module=module, k=k, thres=0.005 / 1000, blocks=[13, 8])
+    want, mds, stats, _ = group_run(oracle, case, [0])
+    got, mds_n, stats_n, size = group_run(hip, case, [0] * n)
+    assert size == n and bits_equal(got, want), n_bit_diff(got, want)
+    assert mds_n == mds and stats_n == stats
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("where", ["own_lo", "own_hi"])
+def test_hip_drain_outlet_next_to_a_slab_boundary(oracle, hip, where):
+    R, C, k = 240, 300, 2
+    case = dict(seed=43, R=R, C=C, module="drain", k=k, thres=0.005 / 1000, blocks=[7, 4],
+                gen=dict(missing_frac=0.0, dry_frac=0.1))
+    b = partition(oracle, R, 2, k)[1].own_lo
+    dr, dc = (b if where == "own_lo" else b - 1), 100
+    want, mds, stats, _ = group_run(oracle, case, [0], dr, dc)
+    got, mds2, stats2, _ = group_run(hip, case, [0, 0], dr, dc)
+    assert bits_equal(got, want) and mds2 == mds and stats2 == stats

@@ -18,6 +18,9 @@ MODULES = {"add": ADD, "subtract": SUBTRACT, "drain": DRAIN}
 KERNEL_AUTO, KERNEL_PASS, KERNEL_FUSED, KERNEL_FUSED2, KERNEL_FUSED2W = 0, 1, 2, 3, 4
 OPT_SIGNED_ZERO_SAFE = 1
 OPT_DEM32 = 2
+HALO_AUTO, HALO_RCCL, HALO_PEER, HALO_HOST = 0, 1, 2, 3
+HALO_NAMES = {0: "none", 1: "rccl", 2: "peer", 3: "host"}
+COMM_ID_BYTES = 128
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # WDPM_HIP_LIB lets a tuning run point at an alternative build of the same HIP library
@@ -35,9 +38,31 @@ class Params(C.Structure):
     ]
 
 
+class SlabStruct(C.Structure):
+    """struct wdpm_slab"""
+    _fields_ = [("own_lo", C.c_int32), ("own_hi", C.c_int32), ("row0", C.c_int32), ("rows", C.c_int32),
+                ("up", C.c_int32), ("down", C.c_int32)]
+
+
+class HaloOp(C.Structure):
+    """struct wdpm_halo_op"""
+    _fields_ = [("peer", C.c_int32), ("row", C.c_int32), ("nrows", C.c_int32)]
+
+
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                          C.POINTER(C.c_void_p), C.POINTER(C.c_int64))
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int32, C.POINTER(C.c_double))
+
+
+class HostTransportStruct(C.Structure):
+    """struct wdpm_host_transport"""
+    _fields_ = [("user", C.c_void_p), ("exchange", EXCHANGE_FN), ("allgather", ALLGATHER_FN)]
+
+
 # name -> (restype, argtypes); every symbol include/wdpm.h declares
 _dp = C.POINTER(C.c_double)
 _vp = C.c_void_p
+_ip = C.POINTER(C.c_int32)
 SYMBOLS = {
     "wdpm_create": (C.c_int, [C.POINTER(_vp), C.POINTER(Params)]),
     "wdpm_destroy": (None, [_vp]),
@@ -67,6 +92,36 @@ SYMBOLS = {
     "wdpm_timing_reset": (C.c_int, [_vp]),
     "wdpm_timing_get": (C.c_int, [_vp, C.POINTER(C.c_int64), _dp]),
     "wdpm_copy_rows": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, C.c_int32]),
+    "wdpm_set_last_error": (None, [C.c_char_p]),
+    "wdpm_enable_peer_access": (C.c_int, [_vp, _vp]),
+    "wdpm_comm_available": (C.c_int, []),
+    "wdpm_comm_version": (C.c_char_p, []),
+    "wdpm_comm_unique_id": (C.c_int, [_vp]),
+    "wdpm_comm_init_rank": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp]),
+    "wdpm_comm_init_all": (C.c_int, [C.POINTER(_vp), C.c_int32]),
+    "wdpm_comm_size": (C.c_int, [_vp, _ip, _ip]),
+    "wdpm_comm_exchange": (C.c_int, [_vp, C.c_int32, C.POINTER(HaloOp), C.c_int32, C.POINTER(HaloOp)]),
+    "wdpm_comm_allgather": (C.c_int, [_vp, _dp, C.c_int32, _dp]),
+    "wdpm_partition": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(SlabStruct)]),
+    "wdpm_rank_create": (C.c_int, [C.POINTER(_vp), C.POINTER(Params), C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp, _vp]),
+    "wdpm_rank_destroy": (None, [_vp]),
+    "wdpm_rank_ctx": (_vp, [_vp]),
+    "wdpm_rank_slab": (C.c_int, [_vp, C.c_int32, C.POINTER(SlabStruct)]),
+    "wdpm_rank_info": (C.c_int, [_vp, _ip, _ip, _ip]),
+    "wdpm_rank_upload": (C.c_int, [_vp, _vp, _vp]),
+    "wdpm_rank_upload_global": (C.c_int, [_vp, _vp, _vp]),
+    "wdpm_rank_set_totaldrain": (C.c_int, [_vp, C.c_double]),
+    "wdpm_rank_get_totaldrain": (C.c_int, [_vp, _dp]),
+    "wdpm_rank_begin_block": (C.c_int, [_vp, C.c_double]),
+    "wdpm_rank_iterate": (C.c_int, [_vp, C.c_int32]),
+    "wdpm_rank_exchange": (C.c_int, [_vp]),
+    "wdpm_rank_max_diff": (C.c_int, [_vp, _dp]),
+    "wdpm_rank_run_block": (C.c_int, [_vp, C.c_int32, C.c_double, _dp]),
+    "wdpm_rank_drain_stats": (C.c_int, [_vp, _dp, _dp]),
+    "wdpm_rank_download_owned": (C.c_int, [_vp, _vp]),
+    "wdpm_group_halo": (C.c_int, [_vp]),
+    "wdpm_group_rank": (_vp, [_vp, C.c_int32]),
+    "wdpm_group_enqueue_stats": (C.c_int, [_vp, _dp, C.POINTER(C.c_int64)]),
     "wdpm_group_create": (C.c_int, [C.POINTER(_vp), C.POINTER(Params), C.c_int32, C.POINTER(C.c_int32), C.c_int32]),
     "wdpm_group_destroy": (None, [_vp]),
     "wdpm_group_size": (C.c_int, [_vp]),

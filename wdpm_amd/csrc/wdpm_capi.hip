@@ -18,18 +18,18 @@
 #include <cstring>
 #include <vector>
 
-#include "../../include/wdpm.h"
-#include "wdpm_kernels.h"
+#include "wdpm_ctx.h"
 
 static thread_local char g_err[512] = "";
 
-static int fail(const char *fmt, ...) {
+int wdpm_fail(const char *fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof g_err, fmt, ap);
   va_end(ap);
   return 1;
 }
+#define fail wdpm_fail
 
 #define HIP_TRY(expr)                                                                         \
   do {                                                                                        \
@@ -37,43 +37,10 @@ static int fail(const char *fmt, ...) {
     if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
   } while (0)
 
-struct EventPair { hipEvent_t a, b; };
-
-struct wdpm_ctx {
-  wdpm_params p;
-  SlabGeom g;
-  size_t cells;
-  hipStream_t stream;
-  bool own_stream;
-  double *d_dem, *d_w[2], *d_old;
-  int cur;
-  double *d_scal;               /* [0] totaldrain, [1] olddrain */
-  unsigned long long *d_bits;   /* max-diff reduction cell */
-  double *h_pin;                /* pinned staging: 4 doubles */
-  double *d_sum_approx;         /* wdpm_volume_partial: per-chunk approximate sums, integer sums, binades, flags */
-  long long *d_sum_i;
-  int *d_sum_k;
-  unsigned *d_sum_flag;
-  int kernel;                   /* resolved WDPM_KERNEL_* */
-  bool signed_zero_safe;        /* a -0.0 depth was uploaded (or the caller asked): exact-zero stencil variant */
-  int *d_dem32;                 /* the DEM as verified-lossless 32-bit codes (wdpm_kernels.h::DemCode) */
-  DemCode code;                 /* code.q == d_dem32 while the uploaded DEM is encodable and the option is on */
-  bool dem32_encodable;
-  /* wdpm_iterate_overlapped: side stream for the interior launch and the event that joins it */
-  hipStream_t side;
-  hipEvent_t ev_fork, ev_join;
-  bool pending_join;
-  hipEvent_t ev_copy[2];        /* wdpm_copy_rows: [0] "my rows are produced" as source, [1] "the copy has read them" as destination */
-  /* stencil timing */
-  std::vector<EventPair> pending;
-  std::vector<EventPair> pool;
-  int64_t launches;
-  double ms;
-};
-
 extern "C" {
 
 const char *wdpm_last_error(void) { return g_err; }
+void wdpm_set_last_error(const char *msg) { snprintf(g_err, sizeof g_err, "%s", msg ? msg : ""); }
 const char *wdpm_backend_name(void) { return "hip-gfx950"; }
 int wdpm_abi_version(void) { return WDPM_ABI_VERSION; }
 
@@ -130,6 +97,8 @@ int wdpm_create(wdpm_ctx **out, const wdpm_params *p) {
   x->signed_zero_safe = false;
   x->launches = 0;
   x->ms = 0.0;
+  x->timing = false;
+  x->comm = nullptr;
   x->d_dem = x->d_w[0] = x->d_w[1] = x->d_old = nullptr;
   x->d_scal = nullptr; x->d_bits = nullptr; x->h_pin = nullptr;
   x->d_dem32 = nullptr; x->code = DemCode{nullptr, 0.0, 1.0, 1.0, 0}; x->dem32_encodable = false;
@@ -170,6 +139,7 @@ void wdpm_destroy(wdpm_ctx *x) {
   if (!x) return;
   (void)hipSetDevice(x->p.device);
   (void)hipStreamSynchronize(x->stream);
+  wdpm_comm_release(x);
   if (x->side) { (void)hipStreamSynchronize(x->side); (void)hipStreamDestroy(x->side); }
   if (x->ev_fork) (void)hipEventDestroy(x->ev_fork);
   if (x->ev_join) (void)hipEventDestroy(x->ev_join);
@@ -292,11 +262,37 @@ int wdpm_upload_rows(wdpm_ctx *x, int32_t row, int32_t nrows, const double *src)
   return note_negzero(x, row, nrows);
 }
 
+/* Direct peer access between two devices, asked for once per ordered pair: without it
+ * hipMemcpyPeerAsync silently stages through host memory on ROCm.  A refusal (no xGMI/PCIe path) is
+ * remembered and leaves the staged copy in charge - slower, same bits. */
+static int enable_peer(int dev, int peer) {
+  static signed char state[64][64];   /* 0 unknown, 1 enabled, -1 refused */
+  if (dev == peer || dev < 0 || peer < 0 || dev >= 64 || peer >= 64 || state[dev][peer]) return 0;
+  int can = 0;
+  HIP_TRY(hipSetDevice(dev));
+  HIP_TRY(hipDeviceCanAccessPeer(&can, dev, peer));
+  if (can) {
+    const hipError_t e = hipDeviceEnablePeerAccess(peer, 0);
+    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) can = 0;
+    (void)hipGetLastError();
+  }
+  state[dev][peer] = can ? 1 : -1;
+  if (!can) fprintf(stderr, "wdpm: no direct peer access from device %d to device %d; halo copies are staged\n", dev, peer);
+  return 0;
+}
+
+int wdpm_enable_peer_access(wdpm_ctx *a, wdpm_ctx *b) {
+  if (!a || !b) return fail("wdpm_enable_peer_access: null context");
+  if (enable_peer(a->p.device, b->p.device)) return 1;
+  return enable_peer(b->p.device, a->p.device);
+}
+
 int wdpm_copy_rows(wdpm_ctx *dst, int32_t dst_row, wdpm_ctx *src, int32_t src_row, int32_t nrows) {
   if (!dst || !src || dst->g.ncp != src->g.ncp || nrows < 0 || dst_row < 0 || src_row < 0 ||
       dst_row + nrows > dst->g.rows || src_row + nrows > src->g.rows)
     return fail("wdpm_copy_rows: bad row range");
   if (nrows == 0) return 0;
+  if (src->p.device != dst->p.device && wdpm_enable_peer_access(dst, src)) return 1;
   /* Ordered on the device, never on the host: the copy runs on the destination's stream behind
    * everything queued there (its kernels are done with the rows being overwritten), after an event
    * that marks the source's queue (its kernels have produced the rows); the source's later work in
@@ -401,11 +397,15 @@ int wdpm_iterate(wdpm_ctx *x, int32_t n_iter) {
   if (n_iter < 0) return fail("wdpm_iterate: negative iteration count");
   if (n_iter == 0) return 0;
   if (bind(x)) return 1;
-  if (x->pending.size() >= 256 && fold_timing(x)) return 1;
-  EventPair ep;
-  if (!x->pool.empty()) { ep = x->pool.back(); x->pool.pop_back(); }
-  else { HIP_TRY(hipEventCreate(&ep.a)); HIP_TRY(hipEventCreate(&ep.b)); }
-  HIP_TRY(hipEventRecord(ep.a, x->stream));
+  /* stencil timing is opt-in (wdpm_timing_reset switches it on): two event records per call are a
+   * measurable share of a small raster's iteration */
+  EventPair ep{nullptr, nullptr};
+  if (x->timing) {
+    if (x->pending.size() >= 256 && fold_timing(x)) return 1;
+    if (!x->pool.empty()) { ep = x->pool.back(); x->pool.pop_back(); }
+    else { HIP_TRY(hipEventCreate(&ep.a)); HIP_TRY(hipEventCreate(&ep.b)); }
+    HIP_TRY(hipEventRecord(ep.a, x->stream));
+  }
   for (int it = 0; it < n_iter; it++) {
     if ((x->kernel == WDPM_KERNEL_FUSED2 || x->kernel == WDPM_KERNEL_FUSED2W) && x->p.module != WDPM_DRAIN &&
         n_iter - it >= 2) {
@@ -432,8 +432,10 @@ int wdpm_iterate(wdpm_ctx *x, int32_t n_iter) {
     if (x->p.module == WDPM_DRAIN)
       HIP_TRY(wdpm_launch_drain_outlet(x->d_w[x->cur], x->d_dem, x->g, x->d_scal, x->stream));
   }
-  HIP_TRY(hipEventRecord(ep.b, x->stream));
-  x->pending.push_back(ep);
+  if (x->timing) {
+    HIP_TRY(hipEventRecord(ep.b, x->stream));
+    x->pending.push_back(ep);
+  }
   return 0;
 }
 
@@ -456,11 +458,13 @@ int wdpm_iterate_overlapped(wdpm_ctx *x, int32_t n_iter, int32_t top_rows, int32
   const int szs = x->signed_zero_safe ? 1 : 0;
   /* stencil timing of this iteration: from here on the main stream to the end of the interior launch
    * on the side stream (the longest of the three) */
-  if (x->pending.size() >= 256 && fold_timing(x)) return 1;
-  EventPair ep;
-  if (!x->pool.empty()) { ep = x->pool.back(); x->pool.pop_back(); }
-  else { HIP_TRY(hipEventCreate(&ep.a)); HIP_TRY(hipEventCreate(&ep.b)); }
-  HIP_TRY(hipEventRecord(ep.a, x->stream));
+  EventPair ep{nullptr, nullptr};
+  if (x->timing) {
+    if (x->pending.size() >= 256 && fold_timing(x)) return 1;
+    if (!x->pool.empty()) { ep = x->pool.back(); x->pool.pop_back(); }
+    else { HIP_TRY(hipEventCreate(&ep.a)); HIP_TRY(hipEventCreate(&ep.b)); }
+    HIP_TRY(hipEventRecord(ep.a, x->stream));
+  }
   HIP_TRY(hipEventRecord(x->ev_fork, x->stream));               /* w_in is complete here */
   if (t_last >= 0)
     HIP_TRY(wdpm_launch_fused_rows(x->p.module, w_in, w_out, x->d_dem, x->code, x->g, 0, t_last, x->p.chunk_rows, szs,
@@ -471,8 +475,10 @@ int wdpm_iterate_overlapped(wdpm_ctx *x, int32_t n_iter, int32_t top_rows, int32
   HIP_TRY(hipStreamWaitEvent(x->side, x->ev_fork, 0));
   HIP_TRY(wdpm_launch_fused_rows(x->p.module, w_in, w_out, x->d_dem, x->code, x->g, t_last >= 0 ? t_last - 1 : 0,
                                  b_first < rows ? b_first - 1 : rows - 1, x->p.chunk_rows, szs, x->d_scal, x->side));
-  HIP_TRY(hipEventRecord(ep.b, x->side));
-  x->pending.push_back(ep);
+  if (x->timing) {
+    HIP_TRY(hipEventRecord(ep.b, x->side));
+    x->pending.push_back(ep);
+  }
   HIP_TRY(hipEventRecord(x->ev_join, x->side));
   x->pending_join = true;
   x->cur ^= 1;
@@ -596,6 +602,7 @@ int wdpm_timing_reset(wdpm_ctx *x) {
   if (fold_timing(x)) return 1;
   x->launches = 0;
   x->ms = 0.0;
+  x->timing = true;
   return 0;
 }
 

@@ -1,0 +1,57 @@
+/*
+ * wdpm_ctx.h — the context object behind the opaque wdpm_ctx of include/wdpm.h (HIP back-end).
+ * Internal to the product library: shared by wdpm_capi.hip (block loop) and wdpm_rccl.hip (RCCL halos).
+ */
+#ifndef WDPM_CTX_H
+#define WDPM_CTX_H
+
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "../../include/wdpm.h"
+#include "wdpm_kernels.h"
+
+struct wdpm_comm;   /* RCCL communicator state of a context (wdpm_rccl.hip) */
+
+struct EventPair { hipEvent_t a, b; };
+
+struct wdpm_ctx {
+  wdpm_params p;
+  SlabGeom g;
+  size_t cells;
+  hipStream_t stream;
+  bool own_stream;
+  double *d_dem, *d_w[2], *d_old;
+  int cur;
+  double *d_scal;               /* [0] totaldrain, [1] olddrain */
+  unsigned long long *d_bits;   /* max-diff reduction cell */
+  double *h_pin;                /* pinned staging: 4 doubles */
+  double *d_sum_approx;         /* wdpm_volume_partial: per-chunk approximate sums, integer sums, binades, flags */
+  long long *d_sum_i;
+  int *d_sum_k;
+  unsigned *d_sum_flag;
+  int kernel;                   /* resolved WDPM_KERNEL_* */
+  bool signed_zero_safe;        /* a -0.0 depth was uploaded (or the caller asked): exact-zero stencil variant */
+  int *d_dem32;                 /* the DEM as verified-lossless 32-bit codes (wdpm_kernels.h::DemCode) */
+  DemCode code;                 /* code.q == d_dem32 while the uploaded DEM is encodable and the option is on */
+  bool dem32_encodable;
+  /* wdpm_iterate_overlapped: side stream for the interior launch and the event that joins it */
+  hipStream_t side;
+  hipEvent_t ev_fork, ev_join;
+  bool pending_join;
+  hipEvent_t ev_copy[2];        /* wdpm_copy_rows: [0] "my rows are produced" as source, [1] "the copy has read them" as destination */
+  /* stencil timing */
+  std::vector<EventPair> pending;
+  std::vector<EventPair> pool;
+  int64_t launches;
+  double ms;
+  bool timing;                  /* record the event pairs at all (off until wdpm_timing_reset asks) */
+  wdpm_comm *comm;              /* wdpm_comm_init_rank / wdpm_comm_init_all, or nullptr */
+};
+
+/* sets wdpm_last_error() of the calling thread and returns 1 */
+int wdpm_fail(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+void wdpm_comm_release(wdpm_ctx *x);   /* wdpm_destroy's hook */
+
+#endif

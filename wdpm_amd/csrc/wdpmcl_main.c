@@ -16,8 +16,9 @@
  *   - malformed invocations that make the reference read uninitialised memory (unknown module with
  *     12/13 arguments, short parameter file) print the usage text and exit 42 instead.
  *   - WDPM_DEVICE=<n> selects the HIP device (default 0).  WDPM_GPUS=<N> spreads the raster over
- *     devices 0..N-1 by row blocks (WDPM_DEVICES=a,b,c names them explicitly), exchanging halo rows
- *     every WDPM_EXCHANGE_EVERY iterations (default 4); results do not depend on N.
+ *     devices 0..N-1 by row blocks (WDPM_DEVICES=a,b,c names them explicitly), one host thread per device,
+ *     exchanging halo rows every WDPM_EXCHANGE_EVERY iterations (default 4) by RCCL send/recv
+ *     (WDPM_HALO=peer: peer copies); results do not depend on N.
  */
 #include <ctype.h>
 #include <math.h>
@@ -368,12 +369,21 @@ static void zero_water(raster_state *s, int valid_only) {
   parallel_ranges((size_t)s->R * s->C, zero_water_range, &p);
 }
 
+/* a raster file that exists but cannot be read: the reference dereferences the NULL FILE* and crashes;
+ * say what happened and stop (a SHORT file keeps the reference's behaviour: missing cells stay as they are) */
+static void read_grid_or_die(const char *path, int R, int C, double *dst) {
+  if (asc_read_grid(path, R, C, dst) != 0) {
+    fprintf(stderr, "WDPMCL: cannot read raster file %s\n", path);
+    exit(1);
+  }
+}
+
 /* water-file branch shared by add and subtract: returns 1 when an existing file was read */
 static int load_or_create_water(const run_config *c, raster_state *s) {
   if (!is_null_name(c->water)) {
     if (file_exists(c->water)) {
       printf("%30s\n", "Existing water file found");
-      asc_read_grid(c->water, s->R, s->C, s->water);
+      read_grid_or_die(c->water, s->R, s->C, s->water);
       return 1;
     }
     printf("%30s\n", "Water file missing, will be created");
@@ -484,7 +494,7 @@ static void setup_module(const run_config *c, raster_state *s) {
     if (file_exists(c->scratch)) {                                             /* resume, :668-673 */
       printf("%s\n", "           ");
       printf("%30s\n", "Scratch file found");
-      asc_read_grid(c->scratch, s->R, s->C, s->water);
+      read_grid_or_die(c->scratch, s->R, s->C, s->water);
       prefer_lossless_scratch(c, s);
       resumed = 1;
     } else {
@@ -498,7 +508,7 @@ static void setup_module(const run_config *c, raster_state *s) {
         exit(42);
       }
       printf("%30s\n", "Existing water file found");
-      asc_read_grid(c->water, s->R, s->C, s->water);
+      read_grid_or_die(c->water, s->R, s->C, s->water);
     } else {
       const int read_file = load_or_create_water(c, s);
       /* the reference recomputes the initial volume only on the scratch-name branch (:690-699, :846-855) */
@@ -753,7 +763,7 @@ int main(int argc, char **argv) {
     return 1;
   }
   phase("allocate host rasters");
-  asc_read_grid(cfg.dem, st.R, st.C, st.dem);
+  read_grid_or_die(cfg.dem, st.R, st.C, st.dem);
   phase("read DEM");
   printf("%s\n", "           ");
   printf("%s\n", "           ");
@@ -784,8 +794,13 @@ int main(int argc, char **argv) {
   wdpm_group *ctx = NULL;
   ABI_TRY(wdpm_group_create(&ctx, &p, ndev, devices, getenv("WDPM_EXCHANGE_EVERY") ? atoi(getenv("WDPM_EXCHANGE_EVERY")) : 4));
   ndev = wdpm_group_size(ctx);
-  fprintf(stderr, "WDPMCL: redistribution loop on back-end %s, %d device%s (first: %d)\n", wdpm_backend_name(), ndev,
-          ndev == 1 ? "" : "s, row-block decomposition", devices[0]);
+  {
+    static const char *const halo_name[] = {"", ", halos by RCCL send/recv", ", halos by peer copies", ", halos through the host"};
+    const int hk = wdpm_group_halo(ctx);
+    fprintf(stderr, "WDPMCL: redistribution loop on back-end %s, %d device%s (first: %d)%s\n", wdpm_backend_name(), ndev,
+            ndev == 1 ? "" : "s, row-block decomposition, one host thread per device", devices[0],
+            ndev > 1 && hk >= 0 && hk < 4 ? halo_name[hk] : "");
+  }
   ABI_TRY(wdpm_group_upload(ctx, st.bigdem, st.bigwater));
   if (cfg.module == WDPM_DRAIN) ABI_TRY(wdpm_group_set_totaldrain(ctx, st.totaldrain0));
   phase("create contexts + upload");

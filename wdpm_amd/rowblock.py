@@ -1,33 +1,33 @@
 """Row-block domain decomposition of the WDPM block loop across ranks (one rank = one GPU).
 
-Host-side driver above the C ABI (include/wdpm.h), mirroring the reference's block loop
-(src/WDPMCL.c:1049-1377) for a raster split into contiguous row slabs.  New work relative to the
-reference, which is single-device.
+Python mirror of the C driver ``wdpm_amd/csrc/wdpm_rowblock.c`` (``wdpm_rank_*`` / ``wdpm_group_*`` of
+include/wdpm.h), which holds ALL of the logic — the partition with its halo rule, the exchange
+schedule, the overlapped last iteration, the block loop of src/WDPMCL.c:1049-1377 across ranks, the
+drain module's chained volume sum.  The same C code drives the ranks of one process in ``WDPMCL``
+(``WDPM_GPUS=N``, one host thread per GPU) and the one-process-per-GPU ranks ``bench.py`` starts.
+What is left here is what only the caller can provide:
 
-Exactness.  Rows outside a slab act as NODATA, so the rows next to a slab edge go wrong and the
-error creeps inward at the rate at which a cell can depend on other cells.  Inside a 3x3 block the
-centre depends on all nine cells and every neighbour on the centre and on the neighbours visited
-before it; chaining this over the three column alignments of a row alignment makes every row of
-a block depend on all three.  The block grid moves down one row per row alignment, so per
-iteration an error at the lower slab edge climbs 4 rows in the first iteration and 6 in each
-further one, and an error at the upper edge descends 2 rows, then 3 per iteration: k iterations
-need 3k-1 halo rows above and 6k-2 below when the slab boundary L satisfies L % 3 == 2
-(halo_depth(); tests/test_rowblock.py re-derives both numbers with a cell-level dependency
-("taint") simulation of the pass order, and shows on rasters that the rule is sufficient).  A rank
-that owns rows [L, H] and holds that halo runs k iterations with no communication and its owned
-rows stay bit-identical to the single-device result; the halos are then refreshed from the
-neighbours' owned rows (one send/recv pair per neighbour every k iterations, over RCCL/xGMI when
-the tensors live on GPUs).  The slab's first row L-(3k-1) is a multiple of 3, which keeps the
-colour alignment of every slab equal to the whole raster's.
-tests/test_rowblock.py checks all of this bit-for-bit on CPU ranks (gloo, world size 2 and 3).
+* how the ranks find each other — the 128-byte RCCL id made by rank 0 (``wdpm_comm_unique_id``) is
+  handed to every rank through ``torch.distributed`` (:func:`rccl_id`); from then on halo rows move
+  GPU to GPU by ``ncclSend``/``ncclRecv`` issued by the library on its own stream;
+* a host-staged transport (:class:`HostTransport`: the library stages rows in host memory and calls
+  back; the bytes travel by gloo) for CPU tests against the oracle back-end and for several ranks
+  sharing the one GPU of a test box, which RCCL refuses.
+
+Exactness (derivation in the C file; ``tests/test_rowblock.py`` re-derives the numbers with a
+cell-level dependency simulation): k iterations without communication need 3k-1 halo rows above and
+6k-2 below a slab whose boundaries are = 2 (mod 3); owned rows then stay bit-identical to the
+single-device result.
 """
 from __future__ import annotations
 
+import ctypes as C
 from dataclasses import dataclass
 
 import numpy as np
 
-from .capi import Context, Lib
+from .capi import (HALO_AUTO, HALO_HOST, HALO_RCCL, MODULES, Context, HostTransportStruct, Lib, Params, SlabStruct,
+                   EXCHANGE_FN, ALLGATHER_FN, COMM_ID_BYTES)
 
 
 @dataclass(frozen=True)
@@ -56,242 +56,265 @@ def halo_depth(k: int):
     return 3 * k - 1, 6 * k - 2
 
 
-def partition(nrows: int, nranks: int, k: int) -> list[Slab]:
-    """Split the (nrows+2)-row padded raster into nranks row slabs with halos for k iterations."""
-    P = nrows + 2
-    up, down = halo_depth(k)
-    bounds = [0]
-    for g in range(1, nranks):
-        b = (P * g) // nranks
-        b -= (b - 2) % 3            # boundaries must be = 2 (mod 3)
-        bounds.append(b)
-    bounds.append(P)
-    slabs = []
-    for g in range(nranks):
-        lo, hi = bounds[g], bounds[g + 1] - 1
-        if nranks > 1 and hi - lo + 1 < max(up, down):
-            raise ValueError(f"slab of rank {g} ({hi - lo + 1} rows) is smaller than the halo depth; "
-                             f"use fewer ranks or a smaller exchange interval")
-        r0 = max(lo - up, 0) if g > 0 else 0
-        r1 = min(hi + down, P - 1) if g < nranks - 1 else P - 1
-        assert r0 % 3 == 0
-        slabs.append(Slab(g, nranks, lo, hi, r0, r1 - r0 + 1, lo - r0, r1 - hi))
-    return slabs
+def partition(lib: Lib, nrows: int, nranks: int, k: int, module="add", drainrow: int = -1) -> list[Slab]:
+    """wdpm_partition: the (nrows+2)-row padded raster as nranks row slabs with halos for k iterations."""
+    out = (SlabStruct * nranks)()
+    m = MODULES[module] if isinstance(module, str) else module
+    if lib.dll.wdpm_partition(nrows, nranks, k, m, drainrow, out) != 0:
+        raise ValueError(f"a slab of {nrows + 2} rows / {nranks} ranks is smaller than the halo depth of {k} "
+                         f"iterations; use fewer ranks or a smaller exchange interval")
+    return [Slab(g, nranks, s.own_lo, s.own_hi, s.row0, s.rows, s.up, s.down) for g, s in enumerate(out)]
+
+
+def rccl_id(lib: Lib, dist, rank: int) -> bytes:
+    """the id every rank needs for ncclCommInitRank: made on rank 0, broadcast by torch.distributed"""
+    box = [None]
+    if rank == 0:
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        lib.check(lib.dll.wdpm_comm_unique_id(buf))
+        box[0] = buf.raw
+    dist.broadcast_object_list(box, src=0)
+    return box[0]
 
 
 class HostTransport:
-    """Halo rows travel through host numpy buffers and torch.distributed point-to-point ops (gloo).
-    Works with any backend library; used by the CPU tests and as a fallback."""
+    """The caller's half of WDPM_HALO_HOST: the library hands over host buffers, torch.distributed
+    (gloo) moves them.  Used by the CPU tests and by multi-rank rehearsals on one GPU."""
 
     def __init__(self, dist, group=None):
         self.dist, self.group = dist, group
+        self.error = None
+        self._exchange = EXCHANGE_FN(self._exchange_cb)
+        self._allgather = ALLGATHER_FN(self._allgather_cb)
+        self.struct = HostTransportStruct(None, self._exchange, self._allgather)
 
-    def exchange(self, ctx: Context, sends, recvs):
-        import torch
-        ops, bufs = [], []
-        for peer, row, n in sends:
-            t = torch.from_numpy(ctx.download_rows(row, n))
-            ops.append(self.dist.P2POp(self.dist.isend, t, peer, self.group))
-            bufs.append(t)
-        landing = []
-        for peer, row, n in recvs:
-            t = torch.empty((n, ctx.ncp), dtype=torch.float64)
-            ops.append(self.dist.P2POp(self.dist.irecv, t, peer, self.group))
-            landing.append((row, t))
-        for w in self.dist.batch_isend_irecv(ops):
-            w.wait()
-        for row, t in landing:
-            ctx.upload_rows(row, t.numpy())
+    def _exchange_cb(self, user, n_ops, is_send, peer, buf, count):
+        try:
+            import torch
+            ops = []
+            for i in range(n_ops):
+                n = int(count[i])
+                if n == 0:
+                    continue
+                a = np.ctypeslib.as_array(C.cast(buf[i], C.POINTER(C.c_double)), shape=(n,))
+                t = torch.from_numpy(a)
+                ops.append(self.dist.P2POp(self.dist.isend if is_send[i] else self.dist.irecv, t, int(peer[i]), self.group))
+            for w in self.dist.batch_isend_irecv(ops) if ops else []:
+                w.wait()
+            return 0
+        except Exception as e:  # noqa: BLE001 - must not propagate through the C frame
+            self.error = e
+            return 1
+
+    def _allgather_cb(self, user, mine, n, out):
+        try:
+            import torch
+            world = self.dist.get_world_size(self.group)
+            m = torch.from_numpy(np.ctypeslib.as_array(mine, shape=(n,)).copy())
+            parts = [torch.empty(n, dtype=torch.float64) for _ in range(world)]
+            self.dist.all_gather(parts, m, group=self.group)
+            np.ctypeslib.as_array(out, shape=(world * n,))[:] = torch.cat(parts).numpy()
+            return 0
+        except Exception as e:  # noqa: BLE001
+            self.error = e
+            return 1
 
 
-class _DeviceMemory:
-    """zero-copy view of library-owned HBM for torch (via __cuda_array_interface__)"""
+class _RankContext(Context):
+    """the slab context a wdpm_rank owns (not destroyed from here)"""
 
-    def __init__(self, ptr: int, n: int):
-        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+    def __init__(self, lib, handle, module, nrows, ncols, slab):
+        self.lib, self._h, self.module = lib, handle, module
+        self.nrows, self.ncols, self.ncp = nrows, ncols, ncols + 2
+        self.slab = slab
 
-
-def device_view(torch, ptr: int, rows: int, ncp: int, device):
-    """torch tensor (rows x ncp, fp64) aliasing library-owned device memory at `ptr`"""
-    return torch.as_tensor(_DeviceMemory(ptr, rows * ncp), device=device).view(rows, ncp)
-
-
-class DeviceTransport:
-    """Halo rows go GPU-to-GPU: torch tensors alias the library's water raster in HBM and are handed
-    to torch.distributed (backend nccl = RCCL, over xGMI inside a node) as one batched
-    send/recv group per exchange.  The context runs on torch's current stream so kernels and
-    transfers are ordered on the device without host synchronisation."""
-
-    def __init__(self, dist, device):
-        import torch
-        self.dist, self.torch, self.device = dist, torch, device
-        self._views = {}
-
-    def _view(self, ctx: Context):
-        ptr = ctx.water_ptr()
-        v = self._views.get(ptr)
-        if v is None:
-            v = device_view(self.torch, ptr, ctx.slab.rows, ctx.ncp, self.device)
-            self._views[ptr] = v
-        return v
-
-    def exchange(self, ctx: Context, sends, recvs):
-        w = self._view(ctx)
-        ops = [self.dist.P2POp(self.dist.isend, w[row:row + n], peer) for peer, row, n in sends]
-        ops += [self.dist.P2POp(self.dist.irecv, w[row:row + n], peer) for peer, row, n in recvs]
-        for work in self.dist.batch_isend_irecv(ops):
-            work.wait()
+    def close(self):
+        self._h = None
 
 
 class RowBlockSolver:
-    """The WDPM block loop on one rank's slab.  With nranks == 1 it is the plain single-GPU loop."""
+    """The WDPM block loop on one rank's slab (wdpm_rank_*).  With nranks == 1 it is the plain
+    single-GPU loop.  halo: "rccl" (needs dist, backend nccl or gloo, to hand the id round), "host"
+    (needs a HostTransport) or None = rccl when no transport is given."""
 
     def __init__(self, lib: Lib, module, nrows: int, ncols: int, missingvalue: float, rank: int = 0,
-                 nranks: int = 1, exchange_every: int = 4, transport=None, dist=None, drainrow: int = 0,
-                 draincol: int = 0, fallback_transport=None, overlap: bool = True, **ctx_kw):
-        self.rank, self.nranks, self.k = rank, nranks, max(1, exchange_every)
-        self.slabs = partition(nrows, nranks, self.k)
+                 nranks: int = 1, exchange_every: int = 4, transport: HostTransport | None = None, dist=None,
+                 drainrow: int = 0, draincol: int = 0, device: int = 0, kernel: int = 0, chunk_rows: int = 0,
+                 halo: str | None = None):
+        self.lib, self.rank, self.nranks, self.dist = lib, rank, nranks, dist
+        m = MODULES[module] if isinstance(module, str) else module
+        p = Params(module=m, nrows=nrows, ncols=ncols, drainrow=drainrow, draincol=draincol, slab_row0=0,
+                   slab_rows=0, device=device, kernel=kernel, chunk_rows=chunk_rows, missingvalue=missingvalue)
+        self.transport = transport
+        kind, idbuf, host = HALO_AUTO, None, None
+        if nranks > 1:
+            if halo is None:
+                halo = "host" if transport is not None else "rccl"
+            if halo == "rccl":
+                if dist is None:
+                    raise ValueError("RCCL halos need torch.distributed to hand the communicator id to every rank")
+                kind, idbuf = HALO_RCCL, rccl_id(lib, dist, rank)
+            elif halo == "host":
+                if transport is None:
+                    raise ValueError("host-staged halos need a HostTransport")
+                kind, host = HALO_HOST, C.byref(transport.struct)
+            else:
+                raise ValueError(f"unknown halo transport {halo!r}")
+        h = C.c_void_p()
+        self._check(lib.dll.wdpm_rank_create(C.byref(h), C.byref(p), rank, nranks, exchange_every, kind, idbuf, host))
+        self._h = h
+        self.slabs = [self._slab(g) for g in range(nranks)]
         self.slab = self.slabs[rank]
-        self.transport, self.dist, self.fallback_transport = transport, dist, fallback_transport
-        if nranks > 1 and (transport is None or dist is None):
-            raise ValueError("multi-rank solver needs a transport and torch.distributed")
-        s = self.slab
-        self.ctx = lib.context(module=module, nrows=nrows, ncols=ncols, missingvalue=missingvalue,
-                               drainrow=drainrow, draincol=draincol, slab_row0=s.row0,
-                               slab_rows=s.rows if nranks > 1 else 0, **ctx_kw)
-        self.module = self.ctx.module
-        self.overlap = overlap and nranks > 1
-        self._since_exchange = 0
-        # drain module: the rank whose OWNED rows hold the outlet has the raster's totaldrain
-        self.drain_owner = next((sl.rank for sl in self.slabs if sl.own_lo <= drainrow <= sl.own_hi), 0)
+        halo_kind, k, owner = C.c_int32(), C.c_int32(), C.c_int32()
+        self._check(lib.dll.wdpm_rank_info(h, C.byref(halo_kind), C.byref(k), C.byref(owner)))
+        self.halo_kind, self.k, self.drain_owner = halo_kind.value, k.value, owner.value
+        self.ctx = _RankContext(lib, C.c_void_p(lib.dll.wdpm_rank_ctx(h)), m, nrows, ncols,
+                                self.slab if nranks > 1 else Slab(0, 1, 0, nrows + 1, 0, nrows + 2, 0, 0))
+        self.module = m
+
+    def _check(self, rc):
+        if rc != 0:
+            if self.transport is not None and self.transport.error is not None:
+                err, self.transport.error = self.transport.error, None
+                raise err
+            self.lib.check(rc)
+
+    def _slab(self, g):
+        s = SlabStruct()
+        self.lib.check(self.lib.dll.wdpm_rank_slab(self._h, g, C.byref(s)))
+        return Slab(g, self.nranks, s.own_lo, s.own_hi, s.row0, s.rows, s.up, s.down)
 
     def close(self):
-        self.ctx.close()
+        if self._h:
+            self.ctx.close()
+            self.lib.dll.wdpm_rank_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def rccl_ranks(self) -> int | None:
+        """communicator size as RCCL itself reports it (ncclCommCount), None without RCCL halos"""
+        if self.halo_kind != HALO_RCCL:
+            return None
+        n = C.c_int32()
+        self.lib.check(self.lib.dll.wdpm_comm_size(self.ctx._h, C.byref(n), None))
+        return n.value
 
     # -- data
-    def upload_global(self, bigdem: np.ndarray, bigwater: np.ndarray):
-        s = self.slab
-        self.ctx.upload(bigdem[s.row0:s.row0 + s.rows], bigwater[s.row0:s.row0 + s.rows])
-        self._since_exchange = 0
-        self.agree_on_options()
+    def upload(self, slab_dem: np.ndarray, slab_water: np.ndarray):
+        d, w = Context._arr(slab_dem, self.ctx.shape), Context._arr(slab_water, self.ctx.shape)
+        self._check(self.lib.dll.wdpm_rank_upload(self._h, d.ctypes.data, w.ctypes.data))
 
-    def agree_on_options(self):
-        """A -0.0 depth anywhere in the raster makes every rank use the sign-preserving stencil
-        variant (halo rows may be written straight into device memory by the transport, past the
-        library's own upload scan)."""
-        if self.nranks > 1:
-            import torch
-            from .capi import OPT_SIGNED_ZERO_SAFE
-            t = torch.tensor([self.ctx.get_option(OPT_SIGNED_ZERO_SAFE)], dtype=torch.int64)
-            if self.dist.get_backend() == "nccl":
-                t = t.cuda()
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-            self.ctx.set_option(OPT_SIGNED_ZERO_SAFE, int(t.item()))
+    def upload_global(self, bigdem: np.ndarray, bigwater: np.ndarray):
+        shape = (self.ctx.nrows + 2, self.ctx.ncp)
+        d, w = Context._arr(bigdem, shape), Context._arr(bigwater, shape)
+        self._check(self.lib.dll.wdpm_rank_upload_global(self._h, d.ctypes.data, w.ctypes.data))
 
     def owned_water(self) -> np.ndarray:
         s = self.slab
-        return self.ctx.download_rows(s.lo, s.hi - s.lo)
-
-    # -- halo refresh
-    def _plan(self):
-        s, sends, recvs = self.slab, [], []
-        if s.rank > 0:
-            above = self.slabs[s.rank - 1]
-            sends.append((s.rank - 1, s.lo, above.down))          # my first rows are its lower halo
-            recvs.append((s.rank - 1, 0, s.up))
-        if s.rank < s.nranks - 1:
-            below = self.slabs[s.rank + 1]
-            sends.append((s.rank + 1, s.hi - below.up, below.up))  # my last rows are its upper halo
-            recvs.append((s.rank + 1, s.hi, s.down))
-        return sends, recvs
-
-    def exchange(self):
-        if self.nranks > 1:
-            sends, recvs = self._plan()
-            try:
-                self.transport.exchange(self.ctx, sends, recvs)
-            except Exception as e:  # noqa: BLE001 - e.g. a GPU-direct transport the platform refuses
-                if self.fallback_transport is None:
-                    raise
-                import sys
-                print(f"[wdpm rank {self.rank}] halo transport {type(self.transport).__name__} failed ({e!r}); "
-                      f"switching to {type(self.fallback_transport).__name__}", file=sys.stderr, flush=True)
-                self.transport, self.fallback_transport = self.fallback_transport, None
-                self.transport.exchange(self.ctx, sends, recvs)
-        self._since_exchange = 0
+        out = np.empty((s.own_hi - s.own_lo + 1 if self.nranks > 1 else self.ctx.nrows + 2, self.ctx.ncp))
+        self.lib.check(self.lib.dll.wdpm_rank_download_owned(self._h, out.ctypes.data))
+        return out
 
     # -- the block loop pieces (WDPMCL.c:1055-1125, 1239-1254)
+    def exchange(self):
+        self._check(self.lib.dll.wdpm_rank_exchange(self._h))
+
     def begin_block(self, thres: float):
-        self.ctx.begin_block(thres)
+        self._check(self.lib.dll.wdpm_rank_begin_block(self._h, thres))
 
     def iterate(self, n_iter: int):
-        done = 0
-        while done < n_iter:
-            room = self.k - self._since_exchange
-            if room <= 0:
-                self.exchange()
-                room = self.k
-            step = min(room, n_iter - done)
-            if self.overlap and step == room:
-                # this step ends a group and an exchange follows: produce the rows the neighbours
-                # need first, so that the send/recv overlaps the rest of the last iteration
-                s = self.slab
-                top = s.lo + self.slabs[s.rank - 1].down if s.rank > 0 else 0
-                bottom = s.rows - (s.hi - self.slabs[s.rank + 1].up) if s.rank < s.nranks - 1 else 0
-                self.ctx.iterate_overlapped(step, top, bottom)
-            else:
-                self.ctx.iterate(step)
-            done += step
-            self._since_exchange += step
+        self._check(self.lib.dll.wdpm_rank_iterate(self._h, n_iter))
 
     def max_diff(self) -> float:
-        if self._since_exchange and self.nranks > 1:
-            self.exchange()
-        s = self.slab
-        m = self.ctx.max_diff(s.lo, s.hi)
-        if self.nranks > 1:
-            import torch
-            t = torch.tensor([m], dtype=torch.float64)
-            if self.dist.get_backend() == "nccl":
-                t = t.cuda()
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-            m = float(t.item())
-        return m
+        v = C.c_double()
+        self._check(self.lib.dll.wdpm_rank_max_diff(self._h, C.byref(v)))
+        return v.value
 
     def run_block(self, n_iter: int, thres: float) -> float:
-        self.begin_block(thres)
-        self.iterate(n_iter)
-        return self.max_diff()
+        v = C.c_double()
+        self._check(self.lib.dll.wdpm_rank_run_block(self._h, n_iter, thres, C.byref(v)))
+        return v.value
 
     # -- drain bookkeeping (WDPMCL.c:1257-1268) across ranks
-    def _bcast(self, values, src):
-        import torch
-        t = torch.tensor(values, dtype=torch.float64)
-        if self.dist.get_backend() == "nccl":
-            t = t.cuda()
-        self.dist.broadcast(t, src=src)
-        return [float(v) for v in t.cpu()]
-
     def set_totaldrain(self, v: float):
-        self.ctx.totaldrain = v
+        self._check(self.lib.dll.wdpm_rank_set_totaldrain(self._h, float(v)))
 
     def totaldrain(self) -> float:
-        td = self.ctx.totaldrain
-        return self._bcast([td], self.drain_owner)[0] if self.nranks > 1 else td
+        v = C.c_double()
+        self._check(self.lib.dll.wdpm_rank_get_totaldrain(self._h, C.byref(v)))
+        return v.value
 
     def drain_stats(self):
-        """(|totaldrain - olddrain|, sum of water over valid cells in the reference's row-major
-        order).  The sum is chained rank to rank so that its rounding equals the single-raster sum."""
-        if self.nranks == 1:
-            return self.ctx.drain_stats()
-        import torch
-        s, nccl = self.slab, self.dist.get_backend() == "nccl"
-        run = torch.zeros(1, dtype=torch.float64, device="cuda" if nccl else "cpu")
-        if s.rank > 0:
-            self.dist.recv(run, src=s.rank - 1)
-        part = self.ctx.volume_partial(s.lo, s.hi, float(run.item()))
-        if s.rank < s.nranks - 1:
-            self.dist.send(torch.tensor([part], dtype=torch.float64, device=run.device), dst=s.rank + 1)
-        final_sum = self._bcast([part], s.nranks - 1)[0]
-        diffdrain = self._bcast([self.ctx.drain_stats_diff()], self.drain_owner)[0]
-        return diffdrain, final_sum
+        """(|totaldrain - olddrain|, sum of water over valid cells in the reference's row-major order)"""
+        a, b = C.c_double(), C.c_double()
+        self._check(self.lib.dll.wdpm_rank_drain_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+
+class Group:
+    """wdpm_group_*: the ranks of ONE process, one host thread per device — what the WDPMCL drop-in
+    uses with WDPM_GPUS=N.  devices may repeat (several slabs on one GPU: peer-copy halos)."""
+
+    def __init__(self, lib: Lib, module, nrows: int, ncols: int, missingvalue: float, devices, exchange_every: int = 4,
+                 drainrow: int = 0, draincol: int = 0, kernel: int = 0):
+        self.lib = lib
+        m = MODULES[module] if isinstance(module, str) else module
+        p = Params(module=m, nrows=nrows, ncols=ncols, drainrow=drainrow, draincol=draincol, slab_row0=0,
+                   slab_rows=0, device=0, kernel=kernel, chunk_rows=0, missingvalue=missingvalue)
+        dev = (C.c_int32 * len(devices))(*devices)
+        h = C.c_void_p()
+        lib.check(lib.dll.wdpm_group_create(C.byref(h), C.byref(p), len(devices), dev, exchange_every))
+        self._h, self.shape = h, (nrows + 2, ncols + 2)
+        self.size = lib.dll.wdpm_group_size(h)
+        self.halo_kind = lib.dll.wdpm_group_halo(h)
+
+    def close(self):
+        if self._h:
+            self.lib.dll.wdpm_group_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def rank_ctx(self, i: int) -> C.c_void_p:
+        return C.c_void_p(self.lib.dll.wdpm_rank_ctx(C.c_void_p(self.lib.dll.wdpm_group_rank(self._h, i))))
+
+    def upload(self, bigdem, bigwater):
+        d, w = Context._arr(bigdem, self.shape), Context._arr(bigwater, self.shape)
+        self.lib.check(self.lib.dll.wdpm_group_upload(self._h, d.ctypes.data, w.ctypes.data))
+
+    def download_water(self) -> np.ndarray:
+        out = np.empty(self.shape)
+        self.lib.check(self.lib.dll.wdpm_group_download_water(self._h, out.ctypes.data))
+        return out
+
+    def set_totaldrain(self, v: float):
+        self.lib.check(self.lib.dll.wdpm_group_set_totaldrain(self._h, float(v)))
+
+    def totaldrain(self) -> float:
+        v = C.c_double()
+        self.lib.check(self.lib.dll.wdpm_group_get_totaldrain(self._h, C.byref(v)))
+        return v.value
+
+    def run_block(self, n_iter: int, thres: float) -> float:
+        v = C.c_double()
+        self.lib.check(self.lib.dll.wdpm_group_run_block(self._h, n_iter, thres, C.byref(v)))
+        return v.value
+
+    def drain_stats(self):
+        a, b = C.c_double(), C.c_double()
+        self.lib.check(self.lib.dll.wdpm_group_drain_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def enqueue_stats(self):
+        s, n = C.c_double(), C.c_int64()
+        self.lib.check(self.lib.dll.wdpm_group_enqueue_stats(self._h, C.byref(s), C.byref(n)))
+        return s.value, n.value
