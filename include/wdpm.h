@@ -40,13 +40,10 @@ extern "C" {
 enum { WDPM_ADD = 0, WDPM_SUBTRACT = 1, WDPM_DRAIN = 2 };
 
 /* which stencil kernel implementation wdpm_iterate uses (product library only).
- * AUTO picks FUSED (WDPM_KERNEL=pass|fused|fused2|fused2w in the environment overrides AUTO).  PASS = one launch per colour pass (9 per iteration), the direct
- * analogue of the reference's 9 clEnqueueNDRangeKernel calls (WDPMCL.c:1184-1206);
- * FUSED = one launch per iteration, register-resident marching window;
- * FUSED2 = one launch per TWO iterations of add/subtract (producer/consumer wave pairs, half the
- *          HBM traffic); odd remainders and the drain module use FUSED. */
-enum { WDPM_KERNEL_AUTO = 0, WDPM_KERNEL_PASS = 1, WDPM_KERNEL_FUSED = 2, WDPM_KERNEL_FUSED2 = 3,
-       WDPM_KERNEL_FUSED2W = 4 /* FUSED2 with six columns per lane (384-column strips) */ };
+ * AUTO picks FUSED (WDPM_KERNEL=pass|fused in the environment overrides AUTO).  PASS = one launch per
+ * colour pass (9 per iteration), the direct analogue of the reference's 9 clEnqueueNDRangeKernel calls
+ * (WDPMCL.c:1184-1206); FUSED = one launch per iteration, register-resident marching window. */
+enum { WDPM_KERNEL_AUTO = 0, WDPM_KERNEL_PASS = 1, WDPM_KERNEL_FUSED = 2 };
 
 typedef struct wdpm_ctx wdpm_ctx; /* opaque */
 

@@ -170,115 +170,3 @@ def fused_iteration(win, dem, miss, H=12):
             run_wave(win, wout, dem, miss, strip, chunk)
     assert not np.isnan(wout).any(), "output cells not covered"
     return wout
-
-
-# ---------------------------------------------------------------------------------------------------
-# two iterations per launch: a producer wave runs iteration 1 and hands its finished rows, lane for
-# lane, through an LDS ring to a consumer wave that runs iteration 2 three steps behind it
-# (wdpm_fused.hip: fused2_iteration_kernel).  12 B of HBM traffic per cell-update instead of 24.
-# ---------------------------------------------------------------------------------------------------
-HALO2_L, HALO2_R = 17, 31       # columns given up per TWO fused iterations (worst-case reach 17 / 30)
-STRIP2_OUT = STRIP_IN - HALO2_L - HALO2_R   # 144
-RING_ROWS = 12
-LAG = 3
-
-
-def strip2_geometry(ncp):
-    strips, j = [], 0
-    while True:
-        c0 = STRIP2_OUT * j
-        lo = 0 if j == 0 else c0 + HALO2_L
-        hi = c0 + STRIP_IN - 1 - HALO2_R
-        strips.append((c0, lo, min(hi, ncp - 1)))
-        if hi >= ncp - 1:
-            break
-        j += 1
-    return strips
-
-
-def chunk2_geometry(rows, H):
-    """(A, producer steps, consumer steps, out_lo, out_hi): outputs partition [0, rows)"""
-    assert H % 3 == 0 and H >= 3
-    chunks, i = [], 0
-    while True:
-        A = H * i
-        lo = 0 if i == 0 else A + 5
-        hi = H * (i + 1) + 4
-        chunks.append((A, H // 3 + 5, H // 3 + 3, lo, min(hi, rows - 1)))
-        if hi >= rows - 1:
-            break
-        i += 1
-    return chunks
-
-
-def run_pair(win, wout, dem, miss, strip, chunk):
-    rows, ncp = win.shape
-    c0, oc_lo, oc_hi = strip
-    A, nsA, nsB, or_lo, or_hi = chunk
-    lane = np.arange(LANES)
-    col = [c0 + 3 * lane + j for j in range(3)]
-    colok = [(c < ncp) for c in col]
-
-    def load(src, r):
-        vs = []
-        for j in range(3):
-            v = np.zeros(LANES) if src is not dem else np.full(LANES, INF)
-            if 0 <= r < rows:
-                ok = colok[j]
-                cc = np.where(ok, col[j], 0)
-                if src is dem:
-                    dd = dem[r, cc]
-                    v = np.where(ok & (dd > miss), dd, INF)
-                else:
-                    v = np.where(ok, src[r, cc], 0.0)
-            vs.append(v)
-        return vs
-
-    ring = {}                                    # ring[row % RING_ROWS] = [3 arrays of 64]
-    WA = [[np.zeros(LANES) for _ in range(3)] for _ in range(7)]
-    DA = [[np.full(LANES, INF) for _ in range(3)] for _ in range(7)]
-    WB = [[np.zeros(LANES) for _ in range(3)] for _ in range(7)]
-    DB = [[np.full(LANES, INF) for _ in range(3)] for _ in range(7)]
-    for R in range(nsA + LAG):
-        if R < nsA:                              # producer, step n = R
-            n = R
-            for i in range(3):
-                WA[4 + i], DA[4 + i] = load(win, A + 3 * n + i), load(dem, A + 3 * n + i)
-            stage(WA, DA, 4)
-            stage(WA, DA, 2)
-            stage(WA, DA, 0)
-            for i in range(3):
-                ring[(3 * n - 4 + i) % RING_ROWS] = [WA[i][j].copy() for j in range(3)]
-            for k in range(4):
-                WA[k], DA[k] = WA[k + 3], DA[k + 3]
-        # ---- workgroup barrier ----
-        m = R - LAG
-        if 0 <= m < nsB:                         # consumer, step m
-            for i in range(3):
-                r = A + 3 * m + i
-                w = [x.copy() for x in ring[(3 * m + i) % RING_ROWS]]
-                ok = [(0 <= r < rows) & colok[j] for j in range(3)]
-                WB[4 + i] = [np.where(ok[j], w[j], 0.0) for j in range(3)]
-                DB[4 + i] = load(dem, r)
-            stage(WB, DB, 4)
-            stage(WB, DB, 2)
-            stage(WB, DB, 0)
-            for i in range(3):
-                r = A + 3 * m - 4 + i
-                if or_lo <= r <= or_hi:
-                    for j in range(3):
-                        ok = (col[j] >= oc_lo) & (col[j] <= oc_hi)
-                        wout[r, col[j][ok]] = WB[i][j][ok]
-            for k in range(4):
-                WB[k], DB[k] = WB[k + 3], DB[k + 3]
-
-
-def fused2_iterations(win, dem, miss, H=12):
-    """TWO whole iterations of the add/subtract module on a padded slab, one pass over the raster."""
-    rows, ncp = win.shape
-    wout = np.full_like(win, np.nan)
-    for chunk in chunk2_geometry(rows, H):
-        for strip in strip2_geometry(ncp):
-            run_pair(win, wout, dem, miss, strip, chunk)
-    assert not np.isnan(wout).any(), "output cells not covered"
-    return wout

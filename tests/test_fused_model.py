@@ -31,19 +31,3 @@ def test_geometry_covers_every_cell_once():
         assert chunks[0][2] == 0 and chunks[-1][3] == rows - 1
         for a, b in zip(chunks, chunks[1:]):
             assert b[2] == a[3] + 1 and b[0] % 3 == 0
-
-
-@pytest.mark.parametrize("R,C,H,seed", [(38, 398, 12, 11), (7, 9, 3, 12), (50, 170, 9, 13), (33, 330, 30, 14),
-                                        (20, 600, 6, 15), (1, 1, 3, 16), (64, 50, 300, 17), (40, 144, 24, 18)])
-def test_two_iteration_pipeline_model_matches_oracle(oracle, R, C, H, seed):
-    """producer/consumer wave pair with the LDS row ring: two iterations in one pass over the raster"""
-    from fused_model import fused2_iterations
-    dem, water, miss = random_case(seed, R, C)
-    bd, bw = pad(dem, water, miss)
-    with oracle.context(module="add", nrows=R, ncols=C, missingvalue=miss) as ctx:
-        ctx.upload(bd, bw)
-        w = bw.copy()
-        for _ in range(2):
-            ctx.iterate(2)
-            w = fused2_iterations(w, bd, miss, H)
-            assert n_bit_diff(w, ctx.download_water()) == 0

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """time the stencil kernels on non-square rasters (e.g. the slabs of a multi-GPU run):
-    shape_bench.py rows cols [iters] [kernels: fused,fused2,fused2w] [module: add|drain]
+    shape_bench.py rows cols [iters] [kernels: fused,pass] [module: add|drain]
 The DEM is rounded to 1e-4 m, so the DEM-code path applies as it does to real DEMs (WDPM_DEM32=0 turns it off,
 WDPM_FILL_PERCENT overrides the waves-per-SIMD choice)."""
 import sys, time
@@ -17,7 +17,7 @@ bw = np.where(bd > -99999.0, 0.1, 0.0)
 kw = {}
 if module == "drain":
     k = int(np.argmin(np.where(bd > 0, bd, np.inf))); kw = dict(drainrow=k // (C + 2), draincol=k % (C + 2))
-for name, k in (("fused", wdpm_amd.KERNEL_FUSED), ("fused2", wdpm_amd.KERNEL_FUSED2), ("fused2w", wdpm_amd.KERNEL_FUSED2W)):
+for name, k in (("fused", wdpm_amd.KERNEL_FUSED), ("pass", wdpm_amd.KERNEL_PASS)):
     if only and name not in only: continue
     with lib.context(module=module, nrows=R, ncols=C, missingvalue=-99999.0, kernel=k, **kw) as c:
         c.upload(bd, bw); c.iterate(20); c.synchronize(); c.timing_reset()

@@ -15,7 +15,7 @@ import numpy as np
 
 ADD, SUBTRACT, DRAIN = 0, 1, 2
 MODULES = {"add": ADD, "subtract": SUBTRACT, "drain": DRAIN}
-KERNEL_AUTO, KERNEL_PASS, KERNEL_FUSED, KERNEL_FUSED2, KERNEL_FUSED2W = 0, 1, 2, 3, 4
+KERNEL_AUTO, KERNEL_PASS, KERNEL_FUSED = 0, 1, 2
 OPT_SIGNED_ZERO_SAFE = 1
 OPT_DEM32 = 2
 HALO_AUTO, HALO_RCCL, HALO_PEER, HALO_HOST = 0, 1, 2, 3

@@ -57,6 +57,7 @@ int wdpm_create(wdpm_ctx **out, const wdpm_params *p) {
   if (!out || !p) return fail("wdpm_create: null argument");
   if (p->nrows < 1 || p->ncols < 1) return fail("wdpm_create: bad raster size %d x %d", p->nrows, p->ncols);
   if (p->module < WDPM_ADD || p->module > WDPM_DRAIN) return fail("wdpm_create: bad module %d", p->module);
+  if (p->kernel < WDPM_KERNEL_AUTO || p->kernel > WDPM_KERNEL_FUSED) return fail("wdpm_create: bad kernel selector %d", p->kernel);
   if (p->slab_row0 < 0 || p->slab_row0 % 3 != 0) return fail("wdpm_create: slab_row0 must be a non-negative multiple of 3");
   const int rows = p->slab_rows > 0 ? p->slab_rows : p->nrows + 2;
   if (p->slab_row0 + rows > p->nrows + 2) return fail("wdpm_create: slab exceeds raster");
@@ -82,15 +83,13 @@ int wdpm_create(wdpm_ctx **out, const wdpm_params *p) {
   x->cells = (size_t)rows * x->g.ncp;
   x->kernel = p->kernel;
   if (x->kernel == WDPM_KERNEL_AUTO) {
-    /* The one-iteration kernel.  The two-iterations-per-launch kernels measured between -0.5 % and
-     * +8 % against it depending on slab shape and box (profiles/r01), not enough to make them the
-     * default; WDPM_KERNEL=pass|fused|fused2|fused2w selects one explicitly. */
+    /* The one-iteration kernel; WDPM_KERNEL=pass|fused selects one explicitly.  (Round 1 also carried two
+     * two-iterations-per-launch kernels: -0.5 % .. +8 % against this one depending on slab shape and box,
+     * VALU-bound; they were taken out of the product in round 2 - DESIGN.md §7b.) */
     x->kernel = WDPM_KERNEL_FUSED;
     if (const char *e = getenv("WDPM_KERNEL")) {
       if (!strcmp(e, "pass")) x->kernel = WDPM_KERNEL_PASS;
       else if (!strcmp(e, "fused")) x->kernel = WDPM_KERNEL_FUSED;
-      else if (!strcmp(e, "fused2")) x->kernel = WDPM_KERNEL_FUSED2;
-      else if (!strcmp(e, "fused2w")) x->kernel = WDPM_KERNEL_FUSED2W;
     }
   }
   x->cur = 0;
@@ -407,18 +406,7 @@ int wdpm_iterate(wdpm_ctx *x, int32_t n_iter) {
     HIP_TRY(hipEventRecord(ep.a, x->stream));
   }
   for (int it = 0; it < n_iter; it++) {
-    if ((x->kernel == WDPM_KERNEL_FUSED2 || x->kernel == WDPM_KERNEL_FUSED2W) && x->p.module != WDPM_DRAIN &&
-        n_iter - it >= 2) {
-      if (x->kernel == WDPM_KERNEL_FUSED2W)
-        HIP_TRY(wdpm_launch_fused2w(x->d_w[x->cur], x->d_w[x->cur ^ 1], x->d_dem, x->g, x->p.chunk_rows,
-                                    x->signed_zero_safe ? 1 : 0, x->stream));
-      else
-        HIP_TRY(wdpm_launch_fused2(x->d_w[x->cur], x->d_w[x->cur ^ 1], x->d_dem, x->g, x->p.chunk_rows,
-                                   x->signed_zero_safe ? 1 : 0, x->stream));
-      x->cur ^= 1;
-      x->launches += 1;
-      it++;                      /* this launch was two iterations */
-    } else if (x->kernel == WDPM_KERNEL_FUSED || x->kernel == WDPM_KERNEL_FUSED2 || x->kernel == WDPM_KERNEL_FUSED2W) {
+    if (x->kernel == WDPM_KERNEL_FUSED) {
       HIP_TRY(wdpm_launch_fused(x->p.module, x->d_w[x->cur], x->d_w[x->cur ^ 1], x->d_dem, x->code, x->g, x->p.chunk_rows,
                                 x->signed_zero_safe ? 1 : 0, x->d_scal, x->stream));
       x->cur ^= 1;

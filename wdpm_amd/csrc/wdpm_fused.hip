@@ -36,7 +36,6 @@
  *
  * Results are bit-identical to the serial reference: same operands, same order, fp64, no FMA in
  * the stencil (the DEM decode uses two, on values it has been verified to reproduce exactly).
- * The file also holds the opt-in two-iterations-per-launch kernels (fused2, fused2w).
  */
 #include "wdpm_kernels.h"
 #include "wdpm_stencil.h"
@@ -470,440 +469,6 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// TWO iterations per launch (add / subtract): 12 B of HBM traffic per cell-update instead of 24.
-//
-// The one-iteration kernel above is bound by HBM (profiles/r01: ~4.8 TB/s of real traffic), so the
-// next step is to touch HBM once per two iterations.  Holding a second iteration's window in the
-// same wave would need ~13 rows x 3 columns x (dem + water) = 156 VGPRs on top of everything else;
-// instead two waves of a workgroup form a pipeline over the same strip and chunk:
-//   producer  loads dem + water from HBM, runs iteration 1 exactly like the kernel above, and writes
-//             every finished row - lane for lane, no transpose - into an LDS ring of 12 rows;
-//   consumer  runs three steps behind, takes its water rows from the ring (its dem rows from
-//             HBM/L2: the producer has just pulled them in), runs iteration 2 and stores the result.
-// One s_barrier per step keeps the pair in lockstep.  The dependency cone of two iterations is
-// 17 columns left / 30 right and 5 rows up / 10 down (tests/test_rowblock.py), so a pair loads a
-// 192 x (H+15) block and stores an exact 144 x H block; tests/fused_model.py::fused2_iterations is
-// the numpy model of this schedule, checked bit-for-bit against the oracle.
-// ---------------------------------------------------------------------------------------------
-constexpr int kHalo2L = 17, kHalo2R = 31;                    // 31: strip pitch 144 is a multiple of 3
-constexpr int kStripOut2 = kStripIn - kHalo2L - kHalo2R;     // 144
-constexpr int kRingRows = 12, kLag = 3;
-
-template <bool SZ_SAFE>
-__global__ void __launch_bounds__(256, WDPM_FUSED_MIN_WAVES)
-fused2_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout,
-                        const double *__restrict__ dem, const SlabGeom g, const int nstrips,
-                        const int nitems, const int H) {
-  const int lane = threadIdx.x & 63;
-  const int vb = (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8;      // XCD-contiguous strips
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int pair = wave >> 1;
-  const bool producer = (wave & 1) == 0;
-  const int item = vb * 2 + pair;
-  if (item >= nitems) return;               // both waves of the pair leave; ended waves do not count at s_barrier
-  const int strip = item % nstrips, chunk = item / nstrips;
-  const int c0 = kStripOut2 * strip;
-  const int oc_lo = strip == 0 ? 0 : c0 + kHalo2L;
-  const int oc_hi = c0 + kStripIn - 1 - kHalo2R;
-  const int A = H * chunk;
-  const int nsA = H / 3 + 5, nsB = H / 3 + 3;
-  const int or_lo = chunk == 0 ? 0 : A + 5;
-  int or_hi = H * (chunk + 1) + 4;
-  if (or_hi > g.rows - 1) or_hi = g.rows - 1;
-  const int colb = c0 + 3 * lane;
-  const size_t pitch = (size_t)g.ncp;
-
-  __shared__ double ring_all[2][kRingRows * kStripIn];     // 18 KiB per pair
-  __shared__ double stage_all[2][3 * kStripIn];            // consumer's store transpose, 4.5 KiB per pair
-  double *const ring = ring_all[pair];
-  double *const stage_lds = stage_all[pair];
-
-  int scol[3];
-  {
-    const int lo = oc_lo - c0;
-    const int hi = (oc_hi < g.ncp - 1 ? oc_hi : g.ncp - 1) - c0;
-#pragma unroll
-    for (int k = 0; k < 3; k++) scol[k] = lo + 64 * k + lane < hi ? lo + 64 * k + lane : hi;
-  }
-  double *const dump = wout + (size_t)g.rows * pitch + lane;
-  bool cdr[5] = {false, false, false, false, false};
-  DrainState ds;
-  ds.td = 0.0;
-  ds.hit = false;
-
-  double W[7][3], D[7][3];
-#pragma unroll
-  for (int k = 0; k < 7; k++)
-#pragma unroll
-    for (int j = 0; j < 3; j++) { W[k][j] = 0.0; D[k][j] = WDPM_INF; }
-
-  const bool edge = (c0 + kStripIn > g.ncp) || (A + 3 * (nsA + 1) > g.rows);
-  int voff[3];
-#pragma unroll
-  for (int j = 0; j < 3; j++) voff[j] = 8 * (edge ? (colb + j < g.ncp ? colb + j : g.ncp - 1) : colb + j);
-
-  // three rows starting at slab row r0 of one raster into raw registers (see the kernel above)
-  auto load3 = [&](const double *base, double (&N)[3][3], const int r0) {
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-      int r = r0 + i;
-      r = r < g.rows ? r : g.rows - 1;
-      const double *b = base + (size_t)r * pitch;           // wave-uniform
-#pragma unroll
-      for (int j = 0; j < 3; j++)
-        asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(N[i][j]) : "v"(voff[j]), "s"(b) : "memory");
-    }
-  };
-#define WDPM_WAIT9(N, YOUNGER)                                                                          \
-  asm volatile("s_waitcnt vmcnt(" #YOUNGER ")"                                                          \
-               : "+v"(N[0][0]), "+v"(N[0][1]), "+v"(N[0][2]), "+v"(N[1][0]), "+v"(N[1][1]), "+v"(N[1][2]), \
-                 "+v"(N[2][0]), "+v"(N[2][1]), "+v"(N[2][2])                                            \
-               :                                                                                        \
-               : "memory")
-  // cells outside the slab: dem = +inf, water = 0 (only edge pairs can see any)
-  auto mask_outside = [&](const int r0) {
-    if (edge) {
-#pragma unroll
-      for (int i = 0; i < 3; i++) {
-        const bool row_ok = r0 + i < g.rows;
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-          const bool ok = row_ok & (colb + j < g.ncp);
-          W[4 + i][j] = ok ? W[4 + i][j] : 0.0;
-          D[4 + i][j] = ok ? D[4 + i][j] : WDPM_INF;
-        }
-      }
-    }
-  };
-  auto slide = [&]() {
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-#pragma unroll
-      for (int j = 0; j < 3; j++) { W[k][j] = W[k + 3][j]; D[k][j] = D[k + 3][j]; }
-  };
-  // LDS writes of this wave are complete, then the pair (and its sibling pair) meet
-  auto pair_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-
-  double NW[3][3], ND[3][3];
-  if (producer) {
-    load3(win, NW, A);
-    load3(dem, ND, A);
-    WDPM_WAIT9(NW, 0);
-    WDPM_WAIT9(ND, 0);
-    for (int R = 0; R < nsA + kLag; R++) {
-      if (R < nsA) {
-        const int n = R;
-#pragma unroll
-        for (int i = 0; i < 3; i++)
-#pragma unroll
-          for (int j = 0; j < 3; j++) { W[4 + i][j] = NW[i][j]; D[4 + i][j] = ND[i][j]; }
-        mask_outside(A + 3 * n);
-        load3(win, NW, A + 3 * (n + 1));
-        load3(dem, ND, A + 3 * (n + 1));
-        const int rbase = A + 3 * n - 4;
-        stage<0, SZ_SAFE, 4>(W, D, rbase + 4, 0, cdr, ds);
-        stage<0, SZ_SAFE, 2>(W, D, rbase + 2, 0, cdr, ds);
-        stage<0, SZ_SAFE, 0>(W, D, rbase + 0, 0, cdr, ds);
-        // rows 3n-4 .. 3n-2 have finished iteration 1: hand them to the consumer, lane for lane
-#pragma unroll
-        for (int i = 0; i < 3; i++) {
-          const int slot = (3 * n - 4 + i + 2 * kRingRows) % kRingRows;
-#pragma unroll
-          for (int j = 0; j < 3; j++) ring[slot * kStripIn + 3 * lane + j] = W[i][j];
-        }
-        WDPM_WAIT9(NW, 0);          // no younger memory operations: the producer does not store to HBM
-        WDPM_WAIT9(ND, 0);
-        slide();
-      }
-      pair_barrier();
-    }
-  } else {
-    load3(dem, ND, A);
-    WDPM_WAIT9(ND, 0);
-    for (int R = 0; R < nsA + kLag; R++) {
-      const int m = R - kLag;
-      if (m >= 0 && m < nsB) {
-        // iteration-1 rows 3m .. 3m+2 from the ring (written at least one barrier ago), dem prefetched
-#pragma unroll
-        for (int i = 0; i < 3; i++) {
-          const int slot = (3 * m + i) % kRingRows;
-#pragma unroll
-          for (int j = 0; j < 3; j++) { W[4 + i][j] = ring[slot * kStripIn + 3 * lane + j]; D[4 + i][j] = ND[i][j]; }
-        }
-        mask_outside(A + 3 * m);
-        load3(dem, ND, A + 3 * (m + 1));
-        // the rows staged by the previous step go out now (9 unconditional stores; dump for m = 0)
-        {
-          const int rb = A + 3 * (m - 1) - 4;
-#pragma unroll
-          for (int i = 0; i < 3; i++) {
-            const int r = rb + i;
-            const bool row_ok = r >= or_lo && r <= or_hi;
-            double *const orow = wout + (size_t)(row_ok ? r : 0) * pitch + c0;
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-              const double v = stage_lds[i * kStripIn + scol[k]];
-              __builtin_nontemporal_store(v, row_ok ? orow + scol[k] : dump);
-            }
-          }
-          __builtin_amdgcn_wave_barrier();
-        }
-        const int rbase = A + 3 * m - 4;
-        stage<0, SZ_SAFE, 4>(W, D, rbase + 4, 0, cdr, ds);
-        stage<0, SZ_SAFE, 2>(W, D, rbase + 2, 0, cdr, ds);
-        stage<0, SZ_SAFE, 0>(W, D, rbase + 0, 0, cdr, ds);
-#pragma unroll
-        for (int i = 0; i < 3; i++)
-#pragma unroll
-          for (int j = 0; j < 3; j++) stage_lds[i * kStripIn + 3 * lane + j] = W[i][j];
-        __builtin_amdgcn_wave_barrier();
-        WDPM_WAIT9(ND, 9);          // younger than the dem loads: this step's 9 stores
-        slide();
-      }
-      pair_barrier();
-    }
-    // the last step's rows
-    const int rb = A + 3 * (nsB - 1) - 4;
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-      const int r = rb + i;
-      const bool row_ok = r >= or_lo && r <= or_hi;
-      double *const orow = wout + (size_t)(row_ok ? r : 0) * pitch + c0;
-#pragma unroll
-      for (int k = 0; k < 3; k++) {
-        const double v = stage_lds[i * kStripIn + scol[k]];
-        __builtin_nontemporal_store(v, row_ok ? orow + scol[k] : dump);
-      }
-    }
-  }
-#undef WDPM_WAIT9
-}
-
-// ---------------------------------------------------------------------------------------------
-// Wide variant of the two-iteration kernel: every lane owns SIX columns (two 3x3 blocks per pass),
-// a wave covers a 384-column strip.  One wave per SIMD already saturates HBM (profiles/r01), so the
-// register file can be spent on width instead of occupancy: the two-iteration dependency cone
-// (17 + 30 columns) now costs 12.5 % of the lanes instead of 25 %, the DPP column exchange is
-// shared by twice as many columns, and the two blocks of a lane are independent instruction chains.
-// Same producer / consumer pipeline, ring and barrier protocol as fused2_iteration_kernel.
-// ---------------------------------------------------------------------------------------------
-constexpr int kWideCols = 6;                                     // columns per lane
-constexpr int kWideIn = 64 * kWideCols;                          // 384 columns loaded per wave
-constexpr int kWideOut = kWideIn - kHalo2L - kHalo2R;            // 336 columns stored per pair (multiple of 3)
-
-/* the three column alignments of one row alignment for NC columns per lane (add / subtract) */
-template <bool SZ_SAFE, int S0, int NC>
-__device__ __forceinline__ void stage_wide(double (&W)[7][NC], const double (&D)[7][NC]) {
-  constexpr int NB = NC / 3;
-  DrainState ds;
-  ds.td = 0.0;
-  ds.hit = false;
-  double w[3][NC + 2], d[3][NC + 2];
-#pragma unroll
-  for (int r = 0; r < 3; r++)
-#pragma unroll
-    for (int c = 0; c < NC; c++) { w[r][c] = W[S0 + r][c]; d[r][c] = D[S0 + r][c]; }
-#pragma unroll
-  for (int a = 0; a < 3; a++) {
-    if (a > 0) {
-      // borrow column a-1 of the next lane as extension column NC + a - 1
-#pragma unroll
-      for (int r = 0; r < 3; r++) { w[r][NC + a - 1] = lane_next(w[r][a - 1]); d[r][NC + a - 1] = lane_next(d[r][a - 1]); }
-    }
-#pragma unroll
-    for (int q = 0; q < NB; q++) {
-      const int c = 3 * q + a;
-      block_update<0, SZ_SAFE>(w[0][c], w[0][c + 1], w[0][c + 2], w[1][c], w[1][c + 1], w[1][c + 2], w[2][c], w[2][c + 1],
-                               w[2][c + 2], d[0][c], d[0][c + 1], d[0][c + 2], d[1][c], d[1][c + 1], d[1][c + 2], d[2][c],
-                               d[2][c + 1], d[2][c + 2], false, false, false, false, false, false, ds);
-    }
-  }
-  // hand the two borrowed columns back to lane+1; lane 0 keeps its own
-#pragma unroll
-  for (int r = 0; r < 3; r++) {
-    w[r][0] = lane_prev(w[r][NC], w[r][0]);
-    w[r][1] = lane_prev(w[r][NC + 1], w[r][1]);
-  }
-#pragma unroll
-  for (int r = 0; r < 3; r++)
-#pragma unroll
-    for (int c = 0; c < NC; c++) W[S0 + r][c] = w[r][c];
-}
-
-template <bool SZ_SAFE>
-__global__ void __launch_bounds__(256, 1)
-fused2w_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout,
-                         const double *__restrict__ dem, const SlabGeom g, const int nstrips,
-                         const int nitems, const int H) {
-  constexpr int NC = kWideCols;
-  const int lane = threadIdx.x & 63;
-  const int vb = (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int pair = wave >> 1;
-  const bool producer = (wave & 1) == 0;
-  const int item = vb * 2 + pair;
-  if (item >= nitems) return;
-  const int strip = item % nstrips, chunk = item / nstrips;
-  const int c0 = kWideOut * strip;
-  const int oc_lo = strip == 0 ? 0 : c0 + kHalo2L;
-  const int oc_hi = c0 + kWideIn - 1 - kHalo2R;
-  const int A = H * chunk;
-  const int nsA = H / 3 + 5, nsB = H / 3 + 3;
-  const int or_lo = chunk == 0 ? 0 : A + 5;
-  int or_hi = H * (chunk + 1) + 4;
-  if (or_hi > g.rows - 1) or_hi = g.rows - 1;
-  const int colb = c0 + NC * lane;
-  const size_t pitch = (size_t)g.ncp;
-
-  __shared__ double ring_all[2][kRingRows * kWideIn];      // 36 KiB per pair
-  __shared__ double stage_all[2][3 * kWideIn];             // 9 KiB per pair
-  double *const ring = ring_all[pair];
-  double *const stage_lds = stage_all[pair];
-
-  int scol[NC];                                            // store instruction k writes columns lo + 64k + lane
-  {
-    const int lo = oc_lo - c0;
-    const int hi = (oc_hi < g.ncp - 1 ? oc_hi : g.ncp - 1) - c0;
-#pragma unroll
-    for (int k = 0; k < NC; k++) scol[k] = lo + 64 * k + lane < hi ? lo + 64 * k + lane : hi;
-  }
-  double *const dump = wout + (size_t)g.rows * pitch + lane;
-
-  double W[7][NC], D[7][NC];
-#pragma unroll
-  for (int k = 0; k < 7; k++)
-#pragma unroll
-    for (int j = 0; j < NC; j++) { W[k][j] = 0.0; D[k][j] = WDPM_INF; }
-
-  const bool edge = (c0 + kWideIn > g.ncp) || (A + 3 * (nsA + 1) > g.rows);
-  int voff[NC];
-#pragma unroll
-  for (int j = 0; j < NC; j++) voff[j] = 8 * (colb + j < g.ncp ? colb + j : g.ncp - 1);
-
-  // The prefetched rows land in ACCUMULATION registers ("a" constraints): gfx950's vector memory
-  // loads can target AGPRs directly, the unified file has 256 of them per lane that this kernel does
-  // not otherwise use, and it keeps the in-flight destinations out of the allocator's way (with
-  // "v" destinations it spills them to AGPRs right behind the load, i.e. before the data arrived).
-  auto load3 = [&](const double *base, double (&N)[3][NC], const int r0) {
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-      int r = r0 + i;
-      r = r < g.rows ? r : g.rows - 1;
-      const double *b = base + (size_t)r * pitch;           // wave-uniform
-#pragma unroll
-      for (int j = 0; j < NC; j++)
-        asm volatile("global_load_dwordx2 %0, %1, %2" : "=a"(N[i][j]) : "v"(voff[j]), "s"(b) : "memory");
-    }
-  };
-#define WDPM_WAIT18(N, YOUNGER)                                                                            \
-  asm volatile("s_waitcnt vmcnt(" #YOUNGER ")"                                                             \
-               : "+a"(N[0][0]), "+a"(N[0][1]), "+a"(N[0][2]), "+a"(N[0][3]), "+a"(N[0][4]), "+a"(N[0][5]), \
-                 "+a"(N[1][0]), "+a"(N[1][1]), "+a"(N[1][2]), "+a"(N[1][3]), "+a"(N[1][4]), "+a"(N[1][5]), \
-                 "+a"(N[2][0]), "+a"(N[2][1]), "+a"(N[2][2]), "+a"(N[2][3]), "+a"(N[2][4]), "+a"(N[2][5])  \
-               :                                                                                           \
-               : "memory")
-  auto mask_outside = [&](const int r0) {
-    if (edge) {
-#pragma unroll
-      for (int i = 0; i < 3; i++) {
-        const bool row_ok = r0 + i < g.rows;
-#pragma unroll
-        for (int j = 0; j < NC; j++) {
-          const bool ok = row_ok & (colb + j < g.ncp);
-          W[4 + i][j] = ok ? W[4 + i][j] : 0.0;
-          D[4 + i][j] = ok ? D[4 + i][j] : WDPM_INF;
-        }
-      }
-    }
-  };
-  auto slide = [&]() {
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-#pragma unroll
-      for (int j = 0; j < NC; j++) { W[k][j] = W[k + 3][j]; D[k][j] = D[k + 3][j]; }
-  };
-  auto pair_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-  auto store_rows = [&](const int rb) {
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-      const int r = rb + i;
-      const bool row_ok = r >= or_lo && r <= or_hi;
-      double *const orow = wout + (size_t)(row_ok ? r : 0) * pitch + c0;
-#pragma unroll
-      for (int k = 0; k < NC; k++) {
-        const double v = stage_lds[i * kWideIn + scol[k]];
-        __builtin_nontemporal_store(v, row_ok ? orow + scol[k] : dump);
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-  };
-
-  double ND[3][NC];
-  if (producer) {
-    double NW[3][NC];
-    load3(win, NW, A);
-    load3(dem, ND, A);
-    WDPM_WAIT18(NW, 0);
-    WDPM_WAIT18(ND, 0);
-    for (int R = 0; R < nsA + kLag; R++) {
-      if (R < nsA) {
-        const int n = R;
-#pragma unroll
-        for (int i = 0; i < 3; i++)
-#pragma unroll
-          for (int j = 0; j < NC; j++) { W[4 + i][j] = NW[i][j]; D[4 + i][j] = ND[i][j]; }
-        mask_outside(A + 3 * n);
-        load3(win, NW, A + 3 * (n + 1));
-        load3(dem, ND, A + 3 * (n + 1));
-        stage_wide<SZ_SAFE, 4, NC>(W, D);
-        stage_wide<SZ_SAFE, 2, NC>(W, D);
-        stage_wide<SZ_SAFE, 0, NC>(W, D);
-#pragma unroll
-        for (int i = 0; i < 3; i++) {
-          const int slot = (3 * n - 4 + i + 2 * kRingRows) % kRingRows;
-#pragma unroll
-          for (int j = 0; j < NC; j++) ring[slot * kWideIn + NC * lane + j] = W[i][j];
-        }
-        WDPM_WAIT18(NW, 0);
-        WDPM_WAIT18(ND, 0);
-        slide();
-      }
-      pair_barrier();
-    }
-  } else {
-    load3(dem, ND, A);
-    WDPM_WAIT18(ND, 0);
-    for (int R = 0; R < nsA + kLag; R++) {
-      const int m = R - kLag;
-      if (m >= 0 && m < nsB) {
-#pragma unroll
-        for (int i = 0; i < 3; i++) {
-          const int slot = (3 * m + i) % kRingRows;
-#pragma unroll
-          for (int j = 0; j < NC; j++) { W[4 + i][j] = ring[slot * kWideIn + NC * lane + j]; D[4 + i][j] = ND[i][j]; }
-        }
-        mask_outside(A + 3 * m);
-        load3(dem, ND, A + 3 * (m + 1));
-        store_rows(A + 3 * (m - 1) - 4);                 // 18 unconditional stores (dump for m = 0)
-        stage_wide<SZ_SAFE, 4, NC>(W, D);
-        stage_wide<SZ_SAFE, 2, NC>(W, D);
-        stage_wide<SZ_SAFE, 0, NC>(W, D);
-#pragma unroll
-        for (int i = 0; i < 3; i++)
-#pragma unroll
-          for (int j = 0; j < NC; j++) stage_lds[i * kWideIn + NC * lane + j] = W[i][j];
-        __builtin_amdgcn_wave_barrier();
-        WDPM_WAIT18(ND, 18);         // younger than the dem loads: this step's 18 stores
-        slide();
-      }
-      pair_barrier();
-    }
-    store_rows(A + 3 * (nsB - 1) - 4);
-  }
-#undef WDPM_WAIT18
-}
-
 __global__ void dpp_probe_kernel(int *out) {
   const int lane = threadIdx.x;
   const double v = (double)lane;
@@ -975,64 +540,6 @@ static hipError_t dpp_selfcheck(hipStream_t s) {
   }
   state = ok ? 1 : -1;
   return ok ? hipSuccess : hipErrorUnknown;
-}
-
-template <bool SZ_SAFE>
-static int resident_pairs() {
-  static int cached = 0;
-  if (cached) return cached;
-  int dev = 0, cus = 256, blocks = 2;
-  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, fused2_iteration_kernel<SZ_SAFE>, 256, 0) != hipSuccess || blocks < 1)
-    blocks = 2;
-  cached = cus * blocks * 2;
-  return cached;
-}
-
-/* two iterations (add / subtract) in one pass over the raster: w_in -> w_out */
-hipError_t wdpm_launch_fused2(const double *w_in, double *w_out, const double *dem, const SlabGeom &g,
-                              int chunk_rows, int signed_zero_safe, hipStream_t s) {
-  hipError_t e = dpp_selfcheck(s);
-  if (e != hipSuccess) return e;
-  int nstrips = 1;
-  if (g.ncp > kStripIn - kHalo2R) nstrips = (g.ncp - (kStripIn - kHalo2R) + kStripOut2 - 1) / kStripOut2 + 1;
-  const int slots = signed_zero_safe ? resident_pairs<true>() : resident_pairs<false>();
-  const int H = pick_chunk_rows(g.rows, nstrips, chunk_rows, slots);
-  // chunk i stores rows [H*i+5 (0 for i=0), H*(i+1)+4]; the last must reach row rows-1
-  int nchunks = (g.rows - 5 + H - 1) / H;
-  if (nchunks < 1) nchunks = 1;
-  const int nitems = nstrips * nchunks;
-  const dim3 grid(((nitems + 1) / 2 + 7) / 8 * 8), block(256);
-  if (signed_zero_safe)
-    hipLaunchKernelGGL((fused2_iteration_kernel<true>), grid, block, 0, s, w_in, w_out, dem, g, nstrips, nitems, H);
-  else
-    hipLaunchKernelGGL((fused2_iteration_kernel<false>), grid, block, 0, s, w_in, w_out, dem, g, nstrips, nitems, H);
-  return hipGetLastError();
-}
-
-/* two iterations in one pass, 384-column strips (six columns per lane), one wave per SIMD */
-hipError_t wdpm_launch_fused2w(const double *w_in, double *w_out, const double *dem, const SlabGeom &g,
-                               int chunk_rows, int signed_zero_safe, hipStream_t s) {
-  hipError_t e = dpp_selfcheck(s);
-  if (e != hipSuccess) return e;
-  int nstrips = 1;
-  if (g.ncp > kWideIn - kHalo2R) nstrips = (g.ncp - (kWideIn - kHalo2R) + kWideOut - 1) / kWideOut + 1;
-  static int slots = 0;                       // resident pairs: 2 per CU (one 4-wave workgroup per CU)
-  if (!slots) {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    slots = cus * 2;
-  }
-  const int H = pick_chunk_rows(g.rows, nstrips, chunk_rows, slots);
-  int nchunks = (g.rows - 5 + H - 1) / H;
-  if (nchunks < 1) nchunks = 1;
-  const int nitems = nstrips * nchunks;
-  const dim3 grid(((nitems + 1) / 2 + 7) / 8 * 8), block(256);
-  if (signed_zero_safe)
-    hipLaunchKernelGGL((fused2w_iteration_kernel<true>), grid, block, 0, s, w_in, w_out, dem, g, nstrips, nitems, H);
-  else
-    hipLaunchKernelGGL((fused2w_iteration_kernel<false>), grid, block, 0, s, w_in, w_out, dem, g, nstrips, nitems, H);
-  return hipGetLastError();
 }
 
 hipError_t wdpm_launch_fused(int module, const double *w_in, double *w_out, const double *dem, const DemCode &code,

@@ -60,11 +60,6 @@ hipError_t wdpm_launch_pass(int module, double *w, const double *dem, const Slab
 hipError_t wdpm_launch_fused(int module, const double *w_in, double *w_out, const double *dem, const DemCode &code,
                              const SlabGeom &g, int chunk_rows, int signed_zero_safe, double *totaldrain,
                              hipStream_t s);
-/* two whole iterations of add / subtract in one launch (12 B of HBM traffic per cell-update) */
-hipError_t wdpm_launch_fused2(const double *w_in, double *w_out, const double *dem, const SlabGeom &g,
-                              int chunk_rows, int signed_zero_safe, hipStream_t s);
-hipError_t wdpm_launch_fused2w(const double *w_in, double *w_out, const double *dem, const SlabGeom &g,
-                               int chunk_rows, int signed_zero_safe, hipStream_t s);
 hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out, const double *dem,
                                   const DemCode &code, const SlabGeom &g, int A0, int out_last, int chunk_rows,
                                   int signed_zero_safe, double *totaldrain, hipStream_t s);
