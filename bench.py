@@ -125,13 +125,20 @@ def self_launch(args):
     process has not touched the GPU and will not), relay rank 0's JSON line, return the launcher's status."""
     import socket
     import subprocess
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    p = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}"]
+    for attempt in range(3):
+        if attempt == 0:       # the launcher picks and holds its own rendezvous port
+            rdzv = ["--standalone", "--local-addr", "127.0.0.1"]
+        else:                  # a port that was free a moment ago
+            with socket.socket() as s:
+                s.bind(("127.0.0.1", 0))
+                rdzv = ["--master-addr", "127.0.0.1", "--master-port", str(s.getsockname()[1])]
+        p = subprocess.run(base + rdzv + [os.path.abspath(__file__), *sys.argv[1:]], stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, text=True, env=env)
+        sys.stderr.write(p.stderr)
+        if p.returncode == 0 or "EADDRINUSE" not in p.stderr:
+            break              # only a lost race for the rendezvous port is worth another try
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
     for ln in p.stdout.splitlines():
         if not ln.startswith('{"metric"'):
@@ -239,7 +246,7 @@ def main():
         ranks_used, halo = grp.size, wdpm_amd.HALO_NAMES[grp.halo_kind]
         ctx0 = grp.rank_ctx(0)
         grp.run_block(args.warmup, THRES)           # untimed warm-up steps (ends with a synchronous reduction)
-        e0, _ = grp.enqueue_stats()
+        e0, x0, _ = grp.enqueue_stats()
         lib.check(lib.dll.wdpm_timing_reset(ctx0))
         t0 = time.perf_counter()
         max_diff = grp.run_block(args.steps, THRES)  # exactly K timed steps
@@ -249,8 +256,9 @@ def main():
             stats_s = time.perf_counter() - ts
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        e1, _ = grp.enqueue_stats()
+        e1, x1, _ = grp.enqueue_stats()
         enqueue_us = (e1 - e0) / max(ranks_used, 1) / max(args.steps, 1) * 1e6
+        refresh_us = (x1 - x0) / max(ranks_used, 1) / max(args.steps, 1) * 1e6
         import ctypes as C
         la, ms = C.c_int64(), C.c_double()
         lib.check(lib.dll.wdpm_timing_get(ctx0, C.byref(la), C.byref(ms)))
@@ -265,19 +273,52 @@ def main():
         closer = grp.close
     else:
         # ---- one process per GPU: wdpm_rank_* with RCCL halos (or host-staged ones when ranks share a GPU)
-        transport = HostTransport(dist) if world > 1 and halo == "host" else None
-        mk = dict(rank=rank, nranks=world, exchange_every=args.exchange_every, transport=transport, dist=dist,
-                  device=device, kernel=kernel, halo=halo if world > 1 else None)
-        solver = RowBlockSolver(lib, "add", n, n, MISSING, **mk)
-        bd, bw = build_slab_inputs(lib, n, solver.slab)
-        solver.upload(bd, bw)
+        # the host-staged transport's bytes travel by gloo: its group is made by every rank, up front
+        host_group = dist.new_group(backend="gloo") if world > 1 and backend == "nccl" else None
+        mk = dict(rank=rank, nranks=world, exchange_every=args.exchange_every, dist=dist, device=device, kernel=kernel)
+
+        def make_solver(module, **extra):
+            if world == 1:
+                return RowBlockSolver(lib, module, n, n, MISSING, **mk, **extra)
+            if halo == "rccl":
+                return RowBlockSolver(lib, module, n, n, MISSING, halo="rccl", **mk, **extra)
+            return RowBlockSolver(lib, module, n, n, MISSING, halo="host", transport=HostTransport(dist, host_group),
+                                  **mk, **extra)
+
+        solver, refused = None, ""
+        try:
+            solver = make_solver("add")
+            bd, bw = build_slab_inputs(lib, n, solver.slab)
+            solver.upload(bd, bw)
+            if world > 1:
+                solver.exchange()                      # the first transfer: communicator set-up, peer mappings
+                solver.ctx.synchronize()
+        except Exception as e:  # noqa: BLE001 - a platform that refuses GPU-direct halos
+            refused = f"{type(e).__name__}: {e}"
+        if world > 1 and halo == "rccl":
+            # decided by ALL ranks together (a rank on its own must never change transport): any refusal anywhere
+            # puts every rank on host-staged halos
+            flag = torch.tensor([1.0 if refused else 0.0], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if flag.item() > 0:
+                if rank == 0:
+                    print(f"bench.py: RCCL halos refused ({refused or 'on another rank'}); every rank switches to "
+                          f"host-staged halos", file=sys.stderr, flush=True)
+                if solver is not None:
+                    solver.close()
+                halo, refused = "host (RCCL refused)", ""
+                solver = RowBlockSolver(lib, "add", n, n, MISSING, halo="host", transport=HostTransport(dist, host_group), **mk)
+                bd, bw = build_slab_inputs(lib, n, solver.slab)
+                solver.upload(bd, bw)
+        if refused:
+            raise SystemExit(f"bench.py: {refused}")
         if args.module == "drain":
             # spin the water up with the add module, then hand the state to a drain solver
             solver.run_block(args.drain_spinup, THRES)
             solver.exchange()
             bw = solver.ctx.download_water()
             solver.close()
-            solver = RowBlockSolver(lib, "drain", n, n, MISSING, **mk, **drain_kw)
+            solver = make_solver("drain", **drain_kw)
             s = solver.slab
             if s.rows != bd.shape[0]:
                 # the drain partition keeps the outlet three rows clear of every boundary and moved one: the add
@@ -310,7 +351,7 @@ def main():
         dem32 = bool(solver.ctx.get_option(wdpm_amd.OPT_DEM32)) and args.module == "add"
         own_rows0 = solver.slab.own_hi - solver.slab.own_lo + 1 if world > 1 else n
         decomposition = f"row-block x{world}, one process per GPU" if world > 1 else "single GPU"
-        enqueue_us = None
+        enqueue_us = refresh_us = None
         closer = solver.close
 
     if rank == 0:
@@ -336,7 +377,8 @@ def main():
                        "halo": halo if ranks_used > 1 else None, "rccl_ranks": rccl_ranks,
                        "dist_backend": backend if world > 1 else None,
                        "max_diff_m": max_diff,
-                       **({"enqueue_us_per_iteration_per_rank": enqueue_us} if enqueue_us is not None else {}),
+                       **({"enqueue_us_per_iteration_per_rank": enqueue_us,
+                           "halo_refresh_host_us_per_iteration_per_rank": refresh_us} if enqueue_us is not None else {}),
                        **({"drain_bookkeeping_ms_per_block": stats_s * 1e3} if stats_s is not None else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -245,9 +245,10 @@ int  wdpm_group_set_totaldrain(wdpm_group *grp, double v);
 int  wdpm_group_get_totaldrain(wdpm_group *grp, double *v);
 int  wdpm_group_run_block(wdpm_group *grp, int32_t n_iter, double thres, double *max_diff);
 int  wdpm_group_drain_stats(wdpm_group *grp, double *diffdrain, double *final_sum);
-/* host time the group's threads spent queueing work in wdpm_group_run_block since creation (summed over
- * ranks, seconds) and the iterations ONE rank queued: enqueue cost per iteration and rank */
-int  wdpm_group_enqueue_stats(wdpm_group *grp, double *seconds, int64_t *iterations);
+/* host time the group's threads spent since creation queueing iteration launches and, separately, in halo
+ * refreshes (both summed over ranks, seconds; the launch calls block when the device's queue is full, the
+ * peer transport's refresh includes waiting for the other threads), and the iterations ONE rank queued */
+int  wdpm_group_enqueue_stats(wdpm_group *grp, double *seconds, double *exchange_seconds, int64_t *iterations);
 
 /* -- options -----------------------------------------------------------------------------------
  * WDPM_OPT_SIGNED_ZERO_SAFE (get/set): 1 = the add/subtract stencil must preserve the sign of

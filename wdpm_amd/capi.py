@@ -121,7 +121,7 @@ SYMBOLS = {
     "wdpm_rank_download_owned": (C.c_int, [_vp, _vp]),
     "wdpm_group_halo": (C.c_int, [_vp]),
     "wdpm_group_rank": (_vp, [_vp, C.c_int32]),
-    "wdpm_group_enqueue_stats": (C.c_int, [_vp, _dp, C.POINTER(C.c_int64)]),
+    "wdpm_group_enqueue_stats": (C.c_int, [_vp, _dp, _dp, C.POINTER(C.c_int64)]),
     "wdpm_group_create": (C.c_int, [C.POINTER(_vp), C.POINTER(Params), C.c_int32, C.POINTER(C.c_int32), C.c_int32]),
     "wdpm_group_destroy": (None, [_vp]),
     "wdpm_group_size": (C.c_int, [_vp]),

@@ -90,7 +90,8 @@ struct wdpm_rank {
   wdpm_halo_op sends[2], recvs[2];
   double *stage[4];             /* HOST: staging for sends[0..1], recvs[0..1] */
   int top_rows, bottom_rows;    /* rows a neighbour needs from the top / bottom of the slab */
-  double enqueue_s;             /* host time spent queueing iterations and exchanges */
+  double enqueue_s;             /* host time spent queueing iteration launches */
+  double exchange_s;            /* host time spent in halo refreshes (peer transport: includes waiting for the other threads) */
   int64_t iters;
 };
 
@@ -312,7 +313,16 @@ static int exchange_peer_all(struct wdpm_group *g) {
   return 0;
 }
 
+static int exchange_now(wdpm_rank *r);
+
 int wdpm_rank_exchange(wdpm_rank *r) {
+  const double t0 = now_s();
+  const int rc = exchange_now(r);
+  r->exchange_s += now_s() - t0;
+  return rc;
+}
+
+static int exchange_now(wdpm_rank *r) {
   r->since = 0;
   if (r->n == 1) return 0;
   if (r->halo == WDPM_HALO_RCCL) return wdpm_comm_exchange(r->c, r->nsend, r->sends, r->nrecv, r->recvs);
@@ -347,7 +357,6 @@ int wdpm_rank_begin_block(wdpm_rank *r, double thres) { return wdpm_begin_block(
 
 int wdpm_rank_iterate(wdpm_rank *r, int32_t n_iter) {
   if (n_iter < 0) return rb_fail("wdpm_rank_iterate: negative iteration count");
-  const double t0 = now_s();
   int done = 0;
   while (done < n_iter) {
     int room = r->k - r->since;
@@ -356,6 +365,7 @@ int wdpm_rank_iterate(wdpm_rank *r, int32_t n_iter) {
       room = r->k;
     }
     const int step = r->n == 1 ? n_iter - done : (room < n_iter - done ? room : n_iter - done);
+    const double t0 = now_s();
     if (r->overlap && step == room) {
       /* this step ends a group of k and an exchange follows: produce the rows the neighbours need
        * first, so that the transfer overlaps the interior rows of the last iteration */
@@ -363,10 +373,10 @@ int wdpm_rank_iterate(wdpm_rank *r, int32_t n_iter) {
     } else if (wdpm_iterate(r->c, step)) {
       return 1;
     }
+    r->enqueue_s += now_s() - t0;
     done += step;
     r->since += step;
   }
-  r->enqueue_s += now_s() - t0;
   r->iters += n_iter;
   return 0;
 }
@@ -601,10 +611,11 @@ int wdpm_group_drain_stats(wdpm_group *g, double *diffdrain, double *final_sum) 
   return 0;
 }
 
-int wdpm_group_enqueue_stats(wdpm_group *g, double *seconds, int64_t *iterations) {
-  double s = 0.0;
-  for (int i = 0; i < g->n; i++) s += g->r[i]->enqueue_s;
+int wdpm_group_enqueue_stats(wdpm_group *g, double *seconds, double *exchange_seconds, int64_t *iterations) {
+  double s = 0.0, e = 0.0;
+  for (int i = 0; i < g->n; i++) { s += g->r[i]->enqueue_s; e += g->r[i]->exchange_s; }
   if (seconds) *seconds = s;
+  if (exchange_seconds) *exchange_seconds = e;
   if (iterations) *iterations = g->r[0]->iters;
   return 0;
 }

@@ -315,6 +315,7 @@ class Group:
         return a.value, b.value
 
     def enqueue_stats(self):
-        s, n = C.c_double(), C.c_int64()
-        self.lib.check(self.lib.dll.wdpm_group_enqueue_stats(self._h, C.byref(s), C.byref(n)))
-        return s.value, n.value
+        """(seconds queueing launches, seconds in halo refreshes) summed over ranks, iterations of one rank"""
+        s, e, n = C.c_double(), C.c_double(), C.c_int64()
+        self.lib.check(self.lib.dll.wdpm_group_enqueue_stats(self._h, C.byref(s), C.byref(e), C.byref(n)))
+        return s.value, e.value, n.value
