@@ -15,7 +15,11 @@ reference executable, serial path cpu=0), and writes DATA only:
                       output rasters for the validation trio (validation/validate_WDPM.sh) and
                       for BASELINE configs 1-2
 
-    python tests/golden/make_golden.py
+  full_size.npz       BASELINE configs 3, 4, 5 at FULL size on the synthetic DEMs (wdpm_synth_dem, seed = size):
+                      4096^2 add x20, 16384^2 add x2, 8192^2 add x3 then drain x5 - sha256 of the padded water
+                      raster, an 8-byte hash of every row, sampled rows, max diff and totaldrain
+
+    python tests/golden/make_golden.py [full]      ("full": only full_size.npz)
 """
 import ctypes as C
 import gzip
@@ -266,7 +270,68 @@ def strip_timing(text):
     return "\n".join(out)
 
 
+def row_hashes(w):
+    """first 8 bytes of the sha256 of every row: says WHICH rows differ when the whole-raster hash does"""
+    return np.array([np.frombuffer(hashlib.sha256(r.tobytes()).digest()[:8], dtype=np.uint64)[0] for r in w],
+                    dtype=np.uint64)
+
+
+def make_full_size(ref):
+    """BASELINE configs 3-5 at full size, from the unmodified reference's runoffs()/runoffd()/drain().
+    About a minute of CPU and 12 GB of memory at 16384^2."""
+    import time
+    sys.path.insert(0, ROOT)
+    import wdpm_amd  # only its ctypes binding of OUR C generator (wdpm_synth_dem), loaded from the oracle library
+    gen = wdpm_amd.load(os.path.join(ROOT, "oracle", "_build", "libwdpm_oracle.so"))
+    missing, thres = -99999.0, 0.005 / 1000
+    out, index = {}, []
+
+    def record(name, n, module, w, w_start, bd, td, secs, sample_every, **extra):
+        valid = bd > missing
+        d = np.abs(w - w_start)
+        md = float(d[0, 0])
+        dv = d[valid]
+        if dv.size and float(dv.max()) > md:
+            md = float(dv.max())                                    # WDPMCL.c:1239-1254
+        out[name + "_rowhash"] = row_hashes(w)
+        out[name + "_rows"] = w[::sample_every].copy()
+        index.append(dict(name=name, n=n, module=module, sha256=sha(w), max_diff=md, totaldrain=td,
+                          sample_every=sample_every, ref_seconds=round(secs, 1), **extra))
+        print(name, index[-1]["sha256"][:16], "max_diff", md, "totaldrain", td, f"{secs:.1f} s")
+
+    for name, n, add_iters, drain_iters, every in (("cfg3_add_4096_i20", 4096, 20, 0, 512),
+                                                   ("cfg4_add_16384_i2", 16384, 2, 0, 4096),
+                                                   ("cfg5_drain_8192_a3_d5", 8192, 3, 5, 2048)):
+        dem = gen.synth_dem(n, n)
+        bd, bw = pad(dem, np.full((n, n), 0.1), missing)            # add 100 mm, rof 1.0 on an empty water raster
+        del dem
+        bw[bw < thres] = 0                                          # the block's threshold flush (a no-op here)
+        t = time.perf_counter()
+        ref.ref_setup(n, n, missing, bd.ctypes.data, bw.ctypes.data, 0.0, 0, 0)
+        ref.ref_iterate(ADD, add_iters)
+        w = ref_water(ref, bd.shape)
+        if not drain_iters:
+            record(name, n, ADD, w, bw, bd, 0.0, time.perf_counter() - t, every, add_iters=add_iters)
+            continue
+        k = int(np.argmin(np.where(bd > 0, bd, np.inf)))            # WDPMCL.c:1005-1017 (first row-major minimum)
+        dr, dc = k // (n + 2), k % (n + 2)
+        td0 = max(float(w[dr, dc]), 0.0)                            # :1029
+        w[w < thres] = 0
+        ref.ref_setup(n, n, missing, bd.ctypes.data, w.ctypes.data, td0, dr, dc)
+        ref.ref_iterate(DRAIN, drain_iters)
+        w2 = ref_water(ref, bd.shape)
+        record(name, n, DRAIN, w2, w, bd, ref.ref_get_totaldrain(), time.perf_counter() - t, every,
+               add_iters=add_iters, drain_iters=drain_iters, drainrow=dr, draincol=dc, td0=td0,
+               volume_sum=float(np.add.accumulate(w2[bd > missing])[-1]))
+        del w2
+    out["index_json"] = np.frombuffer(json.dumps(index).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, "full_size.npz"), **out)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "full":
+        make_full_size(load_ref())
+        return
     if not os.path.exists(REF_SO):
         sys.exit("build oracle/_ref first: make -C oracle ref")
     ref = load_ref()
@@ -275,6 +340,7 @@ def main():
         g.write(f.read())
     make_basin5_state(ref)
     make_basin5_cli()
+    make_full_size(ref)
 
 
 if __name__ == "__main__":
