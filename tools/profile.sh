@@ -17,11 +17,12 @@ for d in ('fetch', 'write', 'sq'):
     for f in glob.glob(f'{out}/{d}/*/*_counter_collection.csv'):
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
-            name = 'fused_iteration_kernel' if 'fused' in r['Kernel_Name'] else r['Kernel_Name'].split('(')[0].replace('void ', '').strip()
+            # template arguments kept: <0,..> is add/subtract, <2,..> drain, the third the DEM-code variant
+            name = r['Kernel_Name'].split('(anonymous namespace)::')[-1].split('(')[0].replace('void ', '').strip()
             agg[name][r['Counter_Name']].append(float(r['Counter_Value']))
         for k, c in agg.items():
             for cn, v in c.items():
                 res.setdefault(k, {})[cn] = {"n": len(v), "mean": sum(v) / len(v)}
 json.dump(res, open(out + '/pmc_summary.json', 'w'), indent=1)
-print(json.dumps({k: v for k, v in res.items() if k in ('fused_iteration_kernel', 'flush_snapshot_kernel', 'max_diff_kernel')}, indent=1))
+print(json.dumps({k: v for k, v in res.items() if 'fused' in k or k in ('flush_snapshot_kernel', 'max_diff_kernel')}, indent=1))
 PY
