@@ -202,18 +202,21 @@ __device__ __forceinline__ void stage_impl(double (&W)[7][3], const double (&D)[
 }
 
 /* Drain: the outlet branch of runoffd() costs ten more instructions per neighbour step, and exactly
- * one cell of the raster needs it.  Whether any of the three rows of this stage is the outlet's row
- * is wave-uniform (`near_outlet` is computed on the scalar unit), so all other stages run the plain
- * neighbour step. */
-template <int MODULE, bool SZ_SAFE, int S0>
-__device__ __forceinline__ void stage(double (&W)[7][3], const double (&D)[7][3], const int row_s0,
-                                      const int drain_row, const bool (&cdr)[5], DrainState &ds) {
-  if (MODULE == 2) {
-    const bool near_outlet = row_s0 <= drain_row && drain_row <= row_s0 + 2;     // wave-uniform
-    if (near_outlet) stage_impl<MODULE, SZ_SAFE, S0, true>(W, D, row_s0, drain_row, cdr, ds);
-    else stage_impl<MODULE, SZ_SAFE, S0, false>(W, D, row_s0, drain_row, cdr, ds);
+ * one cell of the raster needs it.  Whether any of the seven rows of this step's window is the outlet's
+ * row is wave-uniform (computed on the scalar unit), so all other steps run the plain neighbour step -
+ * as ONE basic block of three stages, which lets the scheduler overlap the stages' tails and heads
+ * (a test per stage cut the step into three blocks). */
+template <int MODULE, bool SZ_SAFE>
+__device__ __forceinline__ void three_stages(double (&W)[7][3], const double (&D)[7][3], const int rbase,
+                                             const int drain_row, const bool (&cdr)[5], DrainState &ds) {
+  if (MODULE == 2 && drain_row >= rbase && drain_row <= rbase + 6) {           // wave-uniform, rare
+    stage_impl<MODULE, SZ_SAFE, 4, true>(W, D, rbase + 4, drain_row, cdr, ds);   // oi = 1 on rows 3n   .. 3n+2
+    stage_impl<MODULE, SZ_SAFE, 2, true>(W, D, rbase + 2, drain_row, cdr, ds);   // oi = 2 on rows 3n-2 .. 3n
+    stage_impl<MODULE, SZ_SAFE, 0, true>(W, D, rbase + 0, drain_row, cdr, ds);   // oi = 3 on rows 3n-4 .. 3n-2
   } else {
-    stage_impl<MODULE, SZ_SAFE, S0, false>(W, D, row_s0, drain_row, cdr, ds);
+    stage_impl<MODULE, SZ_SAFE, 4, false>(W, D, rbase + 4, drain_row, cdr, ds);
+    stage_impl<MODULE, SZ_SAFE, 2, false>(W, D, rbase + 2, drain_row, cdr, ds);
+    stage_impl<MODULE, SZ_SAFE, 0, false>(W, D, rbase + 0, drain_row, cdr, ds);
   }
 }
 
@@ -421,9 +424,7 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
 
       const int rbase = A + 3 * n - 4;                 // slab row of window slot 0
 #ifndef WDPM_ABLATE_COMPUTE                            /* timing experiments only: memory pattern alone */
-      stage<MODULE, SZ_SAFE, 4>(W, D, rbase + 4, g.dr, cdr, ds);   // oi = 1 on rows 3n   .. 3n+2
-      stage<MODULE, SZ_SAFE, 2>(W, D, rbase + 2, g.dr, cdr, ds);   // oi = 2 on rows 3n-2 .. 3n
-      stage<MODULE, SZ_SAFE, 0>(W, D, rbase + 0, g.dr, cdr, ds);   // oi = 3 on rows 3n-4 .. 3n-2
+      three_stages<MODULE, SZ_SAFE>(W, D, rbase, g.dr, cdr, ds);
 #else
 #pragma unroll
       for (int j = 0; j < 3; j++) W[0][j] += D[0][j] + D[1][j] + D[2][j];   // keep the dem loads alive

@@ -146,7 +146,11 @@ __device__ __forceinline__ void flow_drain_nz(const double dem_c, double &w_c, c
   const double ht = (dem_c + w_c) - nwe;                        // :1977,1988
   const double s = (dem_c - dem_n) + (w_c - w_n);               // :1995-1996
   const double big = __builtin_ldexp(ht, 2200);                 // :1989 the sign of ht as +inf / 0 / -inf
-  const double x = (dem_c > nwe) ? w_c : vmin_f64(s, big);      // :1990-1996
+  // computed on both sides of the select below: with the inline-asm minimum inside one arm of the
+  // ternary the compiler cannot speculate it and builds a divergent branch (s_and_saveexec /
+  // s_cbranch_execz) around EVERY neighbour step - 72 branches per window step, no scheduling across them
+  const double m = vmin_f64(s, big);
+  const double x = (dem_c > nwe) ? w_c : m;                     // :1990-1996
   double f = vmax_f64(x * 0.125, -0.0);                         // :1998 max(flow, 0.0); NaN -> -0.0
   f = vmin_f64(f, w_c);                                         // :1998 min(.., w_c)
   w_c = w_c - __builtin_fabs(f);                                // :1999
