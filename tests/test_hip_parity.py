@@ -439,3 +439,79 @@ def test_volume_sum_is_the_sequential_sum(hip, name):
         half = (R + 2) // 2
         chained = g.volume_partial(half, R + 2, g.volume_partial(0, half, start))
         assert np.float64(chained).view(np.uint64) == np.float64(want).view(np.uint64) or np.isnan(want)
+
+
+@pytest.mark.parametrize("module", ["add", "drain"])
+@pytest.mark.parametrize("kernel", [wdpm_amd.KERNEL_FUSED, wdpm_amd.KERNEL_PASS])
+def test_lazy_flush_and_snapshot_rotation(hip, oracle, module, kernel):
+    """wdpm_begin_block on the HIP back-end copies nothing and flushes nothing by itself: the current raster
+    BECOMES the snapshot and the threshold flush rides on the next iteration's loads (or is applied when
+    somebody reads or writes the raster first).  Every order of calls must still look exactly like the
+    reference's eager flush + copy (WDPMCL.c:1055-1073), which is what the oracle does."""
+    R, C = 70, 260
+    dem, water, miss = random_case(91, R, C)
+    water = np.where(water < 0.05, water * 1e-3, water)          # plenty of cells below the thresholds used
+    bd, bw = pad(dem, water, miss)
+    rng = np.random.default_rng(5)
+    w2 = np.where(bd > miss, 0.2 * rng.random(bd.shape), 0.0)
+    rows = 0.3 * rng.random((4, C + 2))
+    kw = dict(module=module, nrows=R, ncols=C, missingvalue=miss)
+    if module == "drain":
+        dr, dc = find_drain(bd)
+        kw.update(drainrow=dr, draincol=dc)
+    t1, t2 = 1e-3, 4e-3
+
+    scripts = [
+        [("begin", t1), ("maxdiff",)],
+        [("begin", t1), ("download",)],
+        [("begin", t1), ("upload_water", w2), ("iterate", 2), ("maxdiff",), ("download",)],
+        [("begin", t1), ("pass", 1, 1), ("maxdiff",), ("download",)],
+        [("begin", t1), ("iterate", 1), ("maxdiff",), ("begin", t2), ("iterate", 2), ("maxdiff",), ("download",)],
+        [("begin", t1), ("upload_rows", 9, rows), ("iterate", 1), ("maxdiff",), ("download",)],
+        [("begin", t1), ("begin", t2), ("iterate", 3), ("maxdiff",), ("download",)],
+        [("begin", t2), ("begin", t1), ("maxdiff",), ("iterate", 1), ("maxdiff",)],
+        [("begin", t1), ("volume",), ("iterate", 2), ("volume",), ("maxdiff",)],
+        [("iterate", 2), ("begin", t1), ("iterate", 4), ("begin", t2), ("maxdiff",), ("iterate", 1), ("maxdiff",), ("download",)],
+        [("begin", t1), ("iterate_overlapped", 2, 12, 15), ("maxdiff",), ("download",)],
+        [("begin", t1), ("outlet",), ("maxdiff",), ("download",)],
+    ]
+
+    def play(c, script):
+        out = []
+        for op in script:
+            if op[0] == "begin":
+                c.begin_block(op[1])
+            elif op[0] == "maxdiff":
+                out.append(c.max_diff())
+            elif op[0] == "download":
+                out.append(c.download_water())
+            elif op[0] == "upload_water":
+                c.upload_water(op[1])
+            elif op[0] == "upload_rows":
+                c.upload_rows(op[1], op[2])
+            elif op[0] == "iterate":
+                c.iterate(op[1])
+            elif op[0] == "iterate_overlapped":
+                c.iterate_overlapped(op[1], op[2], op[3])
+            elif op[0] == "pass":
+                c.single_pass(op[1], op[2])
+            elif op[0] == "outlet":
+                c.drain_outlet()
+            elif op[0] == "volume":
+                out.append(c.volume_partial(0, R + 2, 0.0))
+        if module == "drain":
+            out.append(c.totaldrain)
+        return out
+
+    for script in scripts:
+        with hip.context(kernel=kernel, **kw) as g, oracle.context(**kw) as o:
+            for c in (g, o):
+                c.upload(bd, bw)
+                c.totaldrain = 0.25
+            got, want = play(g, script), play(o, script)
+        assert len(got) == len(want)
+        for a, b in zip(got, want):
+            if isinstance(a, np.ndarray):
+                assert n_bit_diff(a, b) == 0, [op[0] for op in script]
+            else:
+                assert a == b, ([op[0] for op in script], a, b)

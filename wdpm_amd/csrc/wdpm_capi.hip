@@ -53,6 +53,47 @@ static int bind(wdpm_ctx *x) {
   return 0;
 }
 
+/* The snapshot of a block is not a copy: wdpm_begin_block just declares the current raster to BE the
+ * snapshot (old = cur) and owes it the threshold flush; the next iteration launch reads it - flushing
+ * while it loads - and writes the other two rasters in turn, so the snapshot stays untouched until
+ * wdpm_max_diff reads it (applying the same flush on the fly).  At 16384^2 that is 1.3 ms per block
+ * that no longer exists.  Whoever needs the current raster flushed in memory, or wants to write
+ * into it, asks for that first: */
+static int free_slot(const wdpm_ctx *x) {            /* a raster that is neither current nor the snapshot */
+  for (int i = 0; i < 3; i++)
+    if (i != x->cur && i != x->old) return i;
+  return 0;
+}
+
+/* readers of d_w[cur]: the owed flush is applied in place (cur == old: the snapshot gets it too, idempotently) */
+static int ensure_flushed(wdpm_ctx *x) {
+  if (!x->flush_pending) return 0;
+  HIP_TRY(wdpm_launch_flush_snapshot(x->d_w[x->cur], x->d_w[x->cur], x->cells, x->flush_thres, x->stream));
+  x->flush_pending = false;
+  return 0;
+}
+
+/* in-place writers of d_w[cur] (pass kernels, drain(), partial uploads): the snapshot must survive */
+static int ensure_private(wdpm_ctx *x) {
+  if (x->cur != x->old) return 0;
+  const int t = free_slot(x);
+  if (x->flush_pending) {
+    HIP_TRY(wdpm_launch_flush_snapshot(x->d_w[x->cur], x->d_w[t], x->cells, x->flush_thres, x->stream));
+    x->flush_pending = false;
+  } else {
+    HIP_TRY(hipMemcpyAsync(x->d_w[t], x->d_w[x->cur], x->cells * sizeof(double), hipMemcpyDeviceToDevice, x->stream));
+  }
+  x->cur = t;
+  return 0;
+}
+
+/* a whole new raster is about to be written: no copy needed, just do not overwrite the snapshot */
+static int ensure_fresh_slot(wdpm_ctx *x) {
+  if (ensure_flushed(x)) return 1;
+  if (x->cur == x->old) x->cur = free_slot(x);
+  return 0;
+}
+
 int wdpm_create(wdpm_ctx **out, const wdpm_params *p) {
   if (!out || !p) return fail("wdpm_create: null argument");
   if (p->nrows < 1 || p->ncols < 1) return fail("wdpm_create: bad raster size %d x %d", p->nrows, p->ncols);
@@ -98,7 +139,10 @@ int wdpm_create(wdpm_ctx **out, const wdpm_params *p) {
   x->ms = 0.0;
   x->timing = false;
   x->comm = nullptr;
-  x->d_dem = x->d_w[0] = x->d_w[1] = x->d_old = nullptr;
+  x->d_dem = x->d_w[0] = x->d_w[1] = x->d_w[2] = nullptr;
+  x->old = 2;
+  x->flush_pending = false;
+  x->flush_thres = -__builtin_inf();
   x->d_scal = nullptr; x->d_bits = nullptr; x->h_pin = nullptr;
   x->d_dem32 = nullptr; x->code = DemCode{nullptr, 0.0, 1.0, 1.0, 0}; x->dem32_encodable = false;
   x->d_sum_approx = nullptr; x->d_sum_i = nullptr; x->d_sum_k = nullptr; x->d_sum_flag = nullptr;
@@ -117,13 +161,13 @@ int wdpm_create(wdpm_ctx **out, const wdpm_params *p) {
   /* + 64 doubles behind each water raster: the fused kernel's dump area for masked-out stores */
   if (e == hipSuccess) e = hipMalloc(&x->d_w[0], bytes + 64 * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&x->d_w[1], bytes + 64 * sizeof(double));
-  if (e == hipSuccess) e = hipMalloc(&x->d_old, bytes);
+  if (e == hipSuccess) e = hipMalloc(&x->d_w[2], bytes + 64 * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&x->d_dem32, x->cells * sizeof(int) + 64);
   if (e == hipSuccess) e = hipMalloc(&x->d_scal, 2 * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&x->d_bits, sizeof(unsigned long long));
   if (e == hipSuccess) e = hipHostMalloc(&x->h_pin, 4 * sizeof(double));
   if (e == hipSuccess) e = hipMemsetAsync(x->d_scal, 0, 2 * sizeof(double), x->stream);
-  if (e == hipSuccess) e = hipMemsetAsync(x->d_old, 0, bytes, x->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(x->d_w[2], 0, bytes, x->stream);   /* the snapshot before any block: zeros */
   if (e == hipSuccess) e = hipStreamSynchronize(x->stream);
   if (e != hipSuccess) {
     fail("wdpm_create: device allocation failed: %s", hipGetErrorString(e));
@@ -146,7 +190,7 @@ void wdpm_destroy(wdpm_ctx *x) {
     if (x->ev_copy[i]) (void)hipEventDestroy(x->ev_copy[i]);
   for (auto &ep : x->pending) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
   for (auto &ep : x->pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
-  (void)hipFree(x->d_dem); (void)hipFree(x->d_w[0]); (void)hipFree(x->d_w[1]); (void)hipFree(x->d_old);
+  (void)hipFree(x->d_dem); (void)hipFree(x->d_w[0]); (void)hipFree(x->d_w[1]); (void)hipFree(x->d_w[2]);
   (void)hipFree(x->d_scal); (void)hipFree(x->d_bits); (void)hipFree(x->d_dem32);
   if (x->h_pin) (void)hipHostFree(x->h_pin);
   (void)hipFree(x->d_sum_approx); (void)hipFree(x->d_sum_i); (void)hipFree(x->d_sum_k); (void)hipFree(x->d_sum_flag);
@@ -219,6 +263,7 @@ int wdpm_upload(wdpm_ctx *x, const double *bigdem, const double *bigwater) {
   if (!bigdem || !bigwater) return fail("wdpm_upload: null array");
   if (bind(x)) return 1;
   const size_t bytes = x->cells * sizeof(double);
+  if (ensure_fresh_slot(x)) return 1;
   HIP_TRY(hipMemcpyAsync(x->d_dem, bigdem, bytes, hipMemcpyHostToDevice, x->stream));
   HIP_TRY(hipMemcpyAsync(x->d_w[x->cur], bigwater, bytes, hipMemcpyHostToDevice, x->stream));
   HIP_TRY(wdpm_launch_mark_nodata(x->d_dem, x->cells, x->g.miss, x->stream));
@@ -231,6 +276,7 @@ int wdpm_upload(wdpm_ctx *x, const double *bigdem, const double *bigwater) {
 int wdpm_upload_water(wdpm_ctx *x, const double *bigwater) {
   if (!bigwater) return fail("wdpm_upload_water: null array");
   if (bind(x)) return 1;
+  if (ensure_fresh_slot(x)) return 1;
   HIP_TRY(hipMemcpyAsync(x->d_w[x->cur], bigwater, x->cells * sizeof(double), hipMemcpyHostToDevice, x->stream));
   x->signed_zero_safe = false;
   return note_negzero(x, 0, x->g.rows);
@@ -239,6 +285,7 @@ int wdpm_upload_water(wdpm_ctx *x, const double *bigwater) {
 int wdpm_download_water(wdpm_ctx *x, double *bigwater) {
   if (!bigwater) return fail("wdpm_download_water: null array");
   if (bind(x)) return 1;
+  if (ensure_flushed(x)) return 1;
   HIP_TRY(hipMemcpyAsync(bigwater, x->d_w[x->cur], x->cells * sizeof(double), hipMemcpyDeviceToHost, x->stream));
   HIP_TRY(hipStreamSynchronize(x->stream));
   return 0;
@@ -247,6 +294,7 @@ int wdpm_download_water(wdpm_ctx *x, double *bigwater) {
 int wdpm_download_rows(wdpm_ctx *x, int32_t row, int32_t nrows, double *dst) {
   if (row < 0 || nrows < 0 || row + nrows > x->g.rows || !dst) return fail("wdpm_download_rows: bad row range");
   if (bind(x)) return 1;
+  if (ensure_flushed(x)) return 1;
   HIP_TRY(hipMemcpyAsync(dst, x->d_w[x->cur] + (size_t)row * x->g.ncp, (size_t)nrows * x->g.ncp * sizeof(double),
                          hipMemcpyDeviceToHost, x->stream));
   HIP_TRY(hipStreamSynchronize(x->stream));
@@ -256,6 +304,7 @@ int wdpm_download_rows(wdpm_ctx *x, int32_t row, int32_t nrows, double *dst) {
 int wdpm_upload_rows(wdpm_ctx *x, int32_t row, int32_t nrows, const double *src) {
   if (row < 0 || nrows < 0 || row + nrows > x->g.rows || !src) return fail("wdpm_upload_rows: bad row range");
   if (bind(x)) return 1;
+  if (ensure_private(x)) return 1;
   HIP_TRY(hipMemcpyAsync(x->d_w[x->cur] + (size_t)row * x->g.ncp, src, (size_t)nrows * x->g.ncp * sizeof(double),
                          hipMemcpyHostToDevice, x->stream));
   return note_negzero(x, row, nrows);
@@ -351,13 +400,27 @@ int wdpm_get_totaldrain(wdpm_ctx *x, double *v) {
   return 0;
 }
 
-int wdpm_water_ptr(wdpm_ctx *x, void **ptr) { *ptr = x->d_w[x->cur]; return 0; }
+int wdpm_water_ptr(wdpm_ctx *x, void **ptr) {
+  if (bind(x) || ensure_private(x)) return 1;   /* the caller may write through it */
+  *ptr = x->d_w[x->cur];
+  return 0;
+}
 int wdpm_dem_ptr(wdpm_ctx *x, void **ptr) { *ptr = x->d_dem; return 0; }
 
 /* ---- block loop ------------------------------------------------------------------------- */
 int wdpm_begin_block(wdpm_ctx *x, double thres) {
   if (bind(x)) return 1;
-  HIP_TRY(wdpm_launch_flush_snapshot(x->d_w[x->cur], x->d_old, x->cells, thres, x->stream));
+  if (ensure_flushed(x)) return 1;                       /* a flush still owed from a block that never iterated */
+  if (x->kernel == WDPM_KERNEL_FUSED && !x->signed_zero_safe) {
+    /* no pass over the raster: the current raster becomes the snapshot, the flush rides on the next launch's loads */
+    x->old = x->cur;
+    x->flush_pending = true;
+  } else {
+    const int t = x->cur == x->old ? free_slot(x) : x->old;
+    HIP_TRY(wdpm_launch_flush_snapshot(x->d_w[x->cur], x->d_w[t], x->cells, thres, x->stream));
+    x->old = t;
+  }
+  x->flush_thres = thres;
   HIP_TRY(hipMemcpyAsync(x->d_scal + 1, x->d_scal, sizeof(double), hipMemcpyDeviceToDevice, x->stream)); /* olddrain */
   return 0;
 }
@@ -375,6 +438,7 @@ static int fold_timing(wdpm_ctx *x) {
 }
 
 static int one_pass(wdpm_ctx *x, int oi, int oj) {
+  if (ensure_private(x)) return 1;
   HIP_TRY(wdpm_launch_pass(x->p.module, x->d_w[x->cur], x->d_dem, x->g, oi, oj, x->d_scal, x->stream));
   return 0;
 }
@@ -387,7 +451,7 @@ int wdpm_pass(wdpm_ctx *x, int32_t oi, int32_t oj) {
 
 int wdpm_drain_outlet(wdpm_ctx *x) {
   if (x->p.module != WDPM_DRAIN) return 0;
-  if (bind(x)) return 1;
+  if (bind(x) || ensure_private(x)) return 1;
   HIP_TRY(wdpm_launch_drain_outlet(x->d_w[x->cur], x->d_dem, x->g, x->d_scal, x->stream));
   return 0;
 }
@@ -407,9 +471,12 @@ int wdpm_iterate(wdpm_ctx *x, int32_t n_iter) {
   }
   for (int it = 0; it < n_iter; it++) {
     if (x->kernel == WDPM_KERNEL_FUSED) {
-      HIP_TRY(wdpm_launch_fused(x->p.module, x->d_w[x->cur], x->d_w[x->cur ^ 1], x->d_dem, x->code, x->g, x->p.chunk_rows,
-                                x->signed_zero_safe ? 1 : 0, x->d_scal, x->stream));
-      x->cur ^= 1;
+      if (x->flush_pending && x->signed_zero_safe && ensure_flushed(x)) return 1;   /* no flush-on-load variant of that kernel */
+      const int t = free_slot(x);
+      HIP_TRY(wdpm_launch_fused(x->p.module, x->d_w[x->cur], x->d_w[t], x->d_dem, x->code, x->g, x->p.chunk_rows,
+                                x->signed_zero_safe ? 1 : 0, x->flush_pending ? &x->flush_thres : nullptr, x->d_scal, x->stream));
+      x->cur = t;
+      x->flush_pending = false;
       x->launches += 1;
     } else {
       for (int oi = 1; oi <= 3; oi++)
@@ -441,9 +508,12 @@ int wdpm_iterate_overlapped(wdpm_ctx *x, int32_t n_iter, int32_t top_rows, int32
   if (!usable) return wdpm_iterate(x, n_iter);
   if (n_iter > 1 && wdpm_iterate(x, n_iter - 1)) return 1;
   if (bind(x)) return 1;
+  if (x->flush_pending && x->signed_zero_safe && ensure_flushed(x)) return 1;
+  const int t_slot = free_slot(x);
   const double *w_in = x->d_w[x->cur];
-  double *w_out = x->d_w[x->cur ^ 1];
+  double *w_out = x->d_w[t_slot];
   const int szs = x->signed_zero_safe ? 1 : 0;
+  const double *flush = x->flush_pending ? &x->flush_thres : nullptr;
   /* stencil timing of this iteration: from here on the main stream to the end of the interior launch
    * on the side stream (the longest of the three) */
   EventPair ep{nullptr, nullptr};
@@ -455,21 +525,22 @@ int wdpm_iterate_overlapped(wdpm_ctx *x, int32_t n_iter, int32_t top_rows, int32
   }
   HIP_TRY(hipEventRecord(x->ev_fork, x->stream));               /* w_in is complete here */
   if (t_last >= 0)
-    HIP_TRY(wdpm_launch_fused_rows(x->p.module, w_in, w_out, x->d_dem, x->code, x->g, 0, t_last, x->p.chunk_rows, szs,
+    HIP_TRY(wdpm_launch_fused_rows(x->p.module, w_in, w_out, x->d_dem, x->code, x->g, 0, t_last, x->p.chunk_rows, szs, flush,
                                    x->d_scal, x->stream));
   if (b_first < rows)
     HIP_TRY(wdpm_launch_fused_rows(x->p.module, w_in, w_out, x->d_dem, x->code, x->g, b_first - 2, rows - 1, x->p.chunk_rows,
-                                   szs, x->d_scal, x->stream));
+                                   szs, flush, x->d_scal, x->stream));
   HIP_TRY(hipStreamWaitEvent(x->side, x->ev_fork, 0));
   HIP_TRY(wdpm_launch_fused_rows(x->p.module, w_in, w_out, x->d_dem, x->code, x->g, t_last >= 0 ? t_last - 1 : 0,
-                                 b_first < rows ? b_first - 1 : rows - 1, x->p.chunk_rows, szs, x->d_scal, x->side));
+                                 b_first < rows ? b_first - 1 : rows - 1, x->p.chunk_rows, szs, flush, x->d_scal, x->side));
   if (x->timing) {
     HIP_TRY(hipEventRecord(ep.b, x->side));
     x->pending.push_back(ep);
   }
   HIP_TRY(hipEventRecord(x->ev_join, x->side));
   x->pending_join = true;
-  x->cur ^= 1;
+  x->cur = t_slot;
+  x->flush_pending = false;
   x->launches += 3;
   return 0;
 }
@@ -477,7 +548,9 @@ int wdpm_iterate_overlapped(wdpm_ctx *x, int32_t n_iter, int32_t top_rows, int32
 int wdpm_max_diff(wdpm_ctx *x, int32_t row_lo, int32_t row_hi, double *out) {
   if (row_lo < 0 || row_hi > x->g.rows || row_lo > row_hi || !out) return fail("wdpm_max_diff: bad row range");
   if (bind(x)) return 1;
-  HIP_TRY(wdpm_launch_max_diff(x->d_w[x->cur], x->d_old, x->d_dem, x->g, row_lo, row_hi, x->d_bits, x->stream));
+  if (ensure_flushed(x)) return 1;
+  /* the snapshot may hold the raster as it was BEFORE the block's flush: the kernel applies the flush as it reads */
+  HIP_TRY(wdpm_launch_max_diff(x->d_w[x->cur], x->d_w[x->old], x->flush_thres, x->d_dem, x->g, row_lo, row_hi, x->d_bits, x->stream));
   HIP_TRY(hipMemcpyAsync(x->h_pin, x->d_bits, sizeof(double), hipMemcpyDeviceToHost, x->stream));
   HIP_TRY(hipStreamSynchronize(x->stream));
   *out = x->h_pin[0];
@@ -505,6 +578,7 @@ int wdpm_drain_stats(wdpm_ctx *x, double *diffdrain, double *final_sum) {
 int wdpm_volume_partial(wdpm_ctx *x, int32_t row_lo, int32_t row_hi, double start, double *sum) {
   if (row_lo < 0 || row_hi > x->g.rows || row_lo > row_hi || !sum) return fail("wdpm_volume_partial: bad row range");
   if (bind(x)) return 1;
+  if (ensure_flushed(x)) return 1;
   const size_t first = (size_t)row_lo * x->g.ncp, n = (size_t)(row_hi - row_lo) * x->g.ncp;
   const size_t nchunks = (n + kSeqSumChunk - 1) / kSeqSumChunk;
   if (nchunks == 0) { *sum = start; return 0; }

@@ -22,8 +22,13 @@ struct wdpm_ctx {
   size_t cells;
   hipStream_t stream;
   bool own_stream;
-  double *d_dem, *d_w[2], *d_old;
-  int cur;
+  double *d_dem, *d_w[3];       /* three water rasters: the current one, the iteration kernel's write target, the snapshot */
+  int cur;                      /* d_w[cur] is bigwater */
+  int old;                      /* d_w[old] is oldwater (WDPMCL.c:1069-1073) - possibly still UNFLUSHED, see flush_pending */
+  bool flush_pending;           /* wdpm_begin_block's threshold flush has not been applied yet: cur == old, and the next
+                                   iteration launch applies it while loading (no pass over the raster of its own) */
+  double flush_thres;           /* the threshold of the current block: the flush still owed to d_w[cur] (flush_pending)
+                                   and to the snapshot when wdpm_max_diff reads it; -inf = none */
   double *d_scal;               /* [0] totaldrain, [1] olddrain */
   unsigned long long *d_bits;   /* max-diff reduction cell */
   double *h_pin;                /* pinned staging: 4 doubles */

@@ -234,12 +234,12 @@ struct Prefetched {
   int qe[3][3];
 };
 
-template <int MODULE, bool SZ_SAFE, bool DEM32>
+template <int MODULE, bool SZ_SAFE, bool DEM32, bool FLUSH = false>
 __global__ void __launch_bounds__(256, WDPM_FUSED_MIN_WAVES)
 fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout,
                        const double *__restrict__ dem, const DemCode code, const SlabGeom g, const int nstrips,
                        const int nitems, const int H, const int A0, const int out_last,
-                       double *__restrict__ totaldrain) {
+                       double *__restrict__ totaldrain, const double thres) {
   const int lane = threadIdx.x & 63;
   // Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2; placement is only a
   // speed matter, never correctness): give each XCD a contiguous run of work items so that the
@@ -400,7 +400,8 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
       for (int i = 0; i < 3; i++)
 #pragma unroll
         for (int j = 0; j < 3; j++) {
-          W[4 + i][j] = P.NW[i][j];
+          // FLUSH: the block's threshold flush (WDPMCL.c:1059-1062) applied to the water as it arrives
+          W[4 + i][j] = FLUSH && P.NW[i][j] < thres ? 0.0 : P.NW[i][j];
           if (DEM32) D[4 + i][j] = dem32_decode(EDGE ? P.qe[i][j] : P.qi[i][j], code.k0, code.D, code.rD);
           else D[4 + i][j] = P.ND[i][j];
         }
@@ -544,19 +545,21 @@ static hipError_t dpp_selfcheck(hipStream_t s) {
 }
 
 hipError_t wdpm_launch_fused(int module, const double *w_in, double *w_out, const double *dem, const DemCode &code,
-                             const SlabGeom &g, int chunk_rows, int signed_zero_safe, double *totaldrain,
-                             hipStream_t s) {
-  return wdpm_launch_fused_rows(module, w_in, w_out, dem, code, g, 0, g.rows - 1, chunk_rows, signed_zero_safe,
+                             const SlabGeom &g, int chunk_rows, int signed_zero_safe, const double *flush,
+                             double *totaldrain, hipStream_t s) {
+  return wdpm_launch_fused_rows(module, w_in, w_out, dem, code, g, 0, g.rows - 1, chunk_rows, signed_zero_safe, flush,
                                 totaldrain, s);
 }
 
 /* one iteration restricted to the output rows [A0 + 2 (0 when A0 == 0), out_last]; A0 % 3 == 0 */
 hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out, const double *dem,
                                   const DemCode &code, const SlabGeom &g, int A0, int out_last, int chunk_rows,
-                                  int signed_zero_safe, double *totaldrain, hipStream_t s) {
+                                  int signed_zero_safe, const double *flush, double *totaldrain, hipStream_t s) {
   hipError_t e = dpp_selfcheck(s);
   if (e != hipSuccess) return e;
   if (A0 < 0 || A0 % 3 != 0 || out_last > g.rows - 1 || out_last < A0) return hipErrorInvalidValue;
+  if (flush && signed_zero_safe) return hipErrorInvalidValue;   /* the caller flushes in place for that variant */
+  const double thres = flush ? *flush : 0.0;
   int nstrips = 1;
   if (g.ncp > kStripIn - kHaloR) nstrips = (g.ncp - (kStripIn - kHaloR) + kStripOut - 1) / kStripOut + 1;
   const bool fast = !signed_zero_safe;
@@ -601,15 +604,12 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
   if (nchunks < 1) nchunks = 1;
   const int nitems = nstrips * nchunks;
   const dim3 grid(((nitems + 3) / 4 + 7) / 8 * 8), block(256);   // multiple of 8: see the XCD remap
-  if (module == 2 && fast)
-    hipLaunchKernelGGL((fused_iteration_kernel<2, false, false>), grid, block, 0, s, w_in, w_out, dem, code, g, nstrips, nitems, H, A0, out_last, totaldrain);
-  else if (module == 2)
-    hipLaunchKernelGGL((fused_iteration_kernel<2, true, false>), grid, block, 0, s, w_in, w_out, dem, code, g, nstrips, nitems, H, A0, out_last, totaldrain);
-  else if (dem32)
-    hipLaunchKernelGGL((fused_iteration_kernel<0, false, true>), grid, block, 0, s, w_in, w_out, dem, code, g, nstrips, nitems, H, A0, out_last, totaldrain);
-  else if (fast)
-    hipLaunchKernelGGL((fused_iteration_kernel<0, false, false>), grid, block, 0, s, w_in, w_out, dem, code, g, nstrips, nitems, H, A0, out_last, totaldrain);
-  else
-    hipLaunchKernelGGL((fused_iteration_kernel<0, true, false>), grid, block, 0, s, w_in, w_out, dem, code, g, nstrips, nitems, H, A0, out_last, totaldrain);
+#define WDPM_LAUNCH(...) hipLaunchKernelGGL((fused_iteration_kernel<__VA_ARGS__>), grid, block, 0, s, w_in, w_out, dem, code, g, nstrips, nitems, H, A0, out_last, totaldrain, thres)
+  if (module == 2 && fast) { if (flush) WDPM_LAUNCH(2, false, false, true); else WDPM_LAUNCH(2, false, false, false); }
+  else if (module == 2) WDPM_LAUNCH(2, true, false, false);
+  else if (dem32) { if (flush) WDPM_LAUNCH(0, false, true, true); else WDPM_LAUNCH(0, false, true, false); }
+  else if (fast) { if (flush) WDPM_LAUNCH(0, false, false, true); else WDPM_LAUNCH(0, false, false, false); }
+  else WDPM_LAUNCH(0, true, false, false);
+#undef WDPM_LAUNCH
   return hipGetLastError();
 }

@@ -57,21 +57,24 @@ hipError_t wdpm_launch_pass(int module, double *w, const double *dem, const Slab
 /* one whole iteration (9 passes) fused in one launch: w_in -> w_out (distinct buffers) */
 /* signed_zero_safe = 0 selects the faster add/subtract variant that is exact when the water raster
  * holds no -0.0 (wdpm_stencil.h::flow_add_nz) */
+/* flush != nullptr: every water value is replaced by 0 when it is < *flush as it is loaded (the block's
+ * threshold flush, WDPMCL.c:1055-1065, riding on the first iteration; only with signed_zero_safe == 0) */
 hipError_t wdpm_launch_fused(int module, const double *w_in, double *w_out, const double *dem, const DemCode &code,
-                             const SlabGeom &g, int chunk_rows, int signed_zero_safe, double *totaldrain,
-                             hipStream_t s);
+                             const SlabGeom &g, int chunk_rows, int signed_zero_safe, const double *flush,
+                             double *totaldrain, hipStream_t s);
 hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out, const double *dem,
                                   const DemCode &code, const SlabGeom &g, int A0, int out_last, int chunk_rows,
-                                  int signed_zero_safe, double *totaldrain, hipStream_t s);
+                                  int signed_zero_safe, const double *flush, double *totaldrain, hipStream_t s);
 /* *flag |= 1 if any of the n doubles at p is -0.0 */
 hipError_t wdpm_launch_scan_negzero(const double *p, size_t n, unsigned long long *flag, hipStream_t s);
 /* drain() (WDPMCL.c:1859-1897) on the device */
 hipError_t wdpm_launch_drain_outlet(double *w, const double *dem, const SlabGeom &g, double *totaldrain,
                                     hipStream_t s);
-/* threshold flush + snapshot (WDPMCL.c:1055-1073) */
+/* threshold flush + snapshot (WDPMCL.c:1055-1073); old == w: flush in place only */
 hipError_t wdpm_launch_flush_snapshot(double *w, double *old, size_t cells, double thres, hipStream_t s);
-/* max |w-old| over valid cells of rows [row_lo,row_hi) (+ seed cell 0), result as uint64 bits */
-hipError_t wdpm_launch_max_diff(const double *w, const double *old, const double *dem, const SlabGeom &g,
+/* max |w-flush(old)| over valid cells of rows [row_lo,row_hi) (+ seed cell 0), result as uint64 bits;
+ * flush(v) = v < old_thres ? 0 : v is the block's threshold flush the snapshot may still be owed (-inf: none) */
+hipError_t wdpm_launch_max_diff(const double *w, const double *old, double old_thres, const double *dem, const SlabGeom &g,
                                 int row_lo, int row_hi, unsigned long long *result_bits, hipStream_t s);
 
 #endif

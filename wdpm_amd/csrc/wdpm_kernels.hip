@@ -126,7 +126,7 @@ hipError_t wdpm_launch_drain_outlet(double *w, const double *dem, const SlabGeom
 // flush + snapshot: w<thres -> 0 over the whole padded slab, then old = w.  16 B per lane.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-flush_snapshot_kernel(double *__restrict__ w, double *__restrict__ old, size_t cells, double thres) {
+flush_snapshot_kernel(double *w, double *old, size_t cells, double thres) {   /* old == w: flush in place */
   const size_t npair = cells / 2;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   double2 *w2 = reinterpret_cast<double2 *>(w);
@@ -330,14 +330,17 @@ __device__ __forceinline__ double wave_max(double m) {
 }
 
 __global__ void __launch_bounds__(256)
-max_diff_kernel(const double *__restrict__ w, const double *__restrict__ old, const double *__restrict__ dem,
-                size_t first, size_t last, int seed_cell0, unsigned long long *result_bits) {
+max_diff_kernel(const double *__restrict__ w, const double *__restrict__ old, const double old_thres,
+                const double *__restrict__ dem, size_t first, size_t last, int seed_cell0,
+                unsigned long long *result_bits) {
   __shared__ double part[4];
   double m = 0.0;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = first + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < last; i += stride) {
     if (cell_valid(dem[i]) || (seed_cell0 && i == 0)) {   // WDPMCL.c:1245 seeds with diff[0][0]
-      const double d = fabs(w[i] - old[i]);
+      double o = old[i];
+      if (o < old_thres) o = 0;                           // the flush the snapshot is still owed (WDPMCL.c:1059-1062)
+      const double d = fabs(w[i] - o);
       if (d > m) m = d;
     }
   }
@@ -351,7 +354,7 @@ max_diff_kernel(const double *__restrict__ w, const double *__restrict__ old, co
   }
 }
 
-hipError_t wdpm_launch_max_diff(const double *w, const double *old, const double *dem, const SlabGeom &g,
+hipError_t wdpm_launch_max_diff(const double *w, const double *old, double old_thres, const double *dem, const SlabGeom &g,
                                 int row_lo, int row_hi, unsigned long long *result_bits, hipStream_t s) {
   hipError_t e = hipMemsetAsync(result_bits, 0, sizeof(unsigned long long), s);
   if (e != hipSuccess) return e;
@@ -359,7 +362,7 @@ hipError_t wdpm_launch_max_diff(const double *w, const double *old, const double
   const size_t first = (size_t)row_lo * g.ncp, last = (size_t)row_hi * g.ncp;
   size_t blocks = (last - first + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(max_diff_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w, old, dem, first, last,
+  hipLaunchKernelGGL(max_diff_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w, old, old_thres, dem, first, last,
                      row_lo == 0 ? 1 : 0, result_bits);
   return hipGetLastError();
 }
