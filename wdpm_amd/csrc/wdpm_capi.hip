@@ -65,8 +65,19 @@ static int free_slot(const wdpm_ctx *x) {            /* a raster that is neither
   return 0;
 }
 
+/* Drain module: drain() after each iteration (WDPMCL.c:1089) has no launch of its own either - the next
+ * iteration launch applies it while loading (wdpm_fused.hip: drain_owed).  Anybody else who looks at the
+ * raster or at totaldrain gets it applied first.  (cur != old whenever it is owed: an iteration has run.) */
+static int ensure_drained(wdpm_ctx *x) {
+  if (!x->drain_owed) return 0;
+  x->drain_owed = false;
+  HIP_TRY(wdpm_launch_drain_outlet(x->d_w[x->cur], x->d_dem, x->g, x->d_scal, x->stream));
+  return 0;
+}
+
 /* readers of d_w[cur]: the owed flush is applied in place (cur == old: the snapshot gets it too, idempotently) */
 static int ensure_flushed(wdpm_ctx *x) {
+  if (ensure_drained(x)) return 1;
   if (!x->flush_pending) return 0;
   HIP_TRY(wdpm_launch_flush_snapshot(x->d_w[x->cur], x->d_w[x->cur], x->cells, x->flush_thres, x->stream));
   x->flush_pending = false;
@@ -75,6 +86,7 @@ static int ensure_flushed(wdpm_ctx *x) {
 
 /* in-place writers of d_w[cur] (pass kernels, drain(), partial uploads): the snapshot must survive */
 static int ensure_private(wdpm_ctx *x) {
+  if (ensure_drained(x)) return 1;
   if (x->cur != x->old) return 0;
   const int t = free_slot(x);
   if (x->flush_pending) {
@@ -142,6 +154,7 @@ int wdpm_create(wdpm_ctx **out, const wdpm_params *p) {
   x->d_dem = x->d_w[0] = x->d_w[1] = x->d_w[2] = nullptr;
   x->old = 2;
   x->flush_pending = false;
+  x->drain_owed = false;
   x->flush_thres = -__builtin_inf();
   x->d_scal = nullptr; x->d_bits = nullptr; x->h_pin = nullptr;
   x->d_dem32 = nullptr; x->code = DemCode{nullptr, 0.0, 1.0, 1.0, 0}; x->dem32_encodable = false;
@@ -385,7 +398,7 @@ int wdpm_set_option(wdpm_ctx *x, int32_t key, int64_t value) {
 }
 
 int wdpm_set_totaldrain(wdpm_ctx *x, double v) {
-  if (bind(x)) return 1;
+  if (bind(x) || ensure_drained(x)) return 1;
   x->h_pin[0] = v;
   HIP_TRY(hipMemcpyAsync(x->d_scal, x->h_pin, sizeof(double), hipMemcpyHostToDevice, x->stream));
   HIP_TRY(hipStreamSynchronize(x->stream));
@@ -393,7 +406,7 @@ int wdpm_set_totaldrain(wdpm_ctx *x, double v) {
 }
 
 int wdpm_get_totaldrain(wdpm_ctx *x, double *v) {
-  if (bind(x)) return 1;
+  if (bind(x) || ensure_drained(x)) return 1;
   HIP_TRY(hipMemcpyAsync(x->h_pin, x->d_scal, sizeof(double), hipMemcpyDeviceToHost, x->stream));
   HIP_TRY(hipStreamSynchronize(x->stream));
   *v = x->h_pin[0];
@@ -474,10 +487,13 @@ int wdpm_iterate(wdpm_ctx *x, int32_t n_iter) {
       if (x->flush_pending && x->signed_zero_safe && ensure_flushed(x)) return 1;   /* no flush-on-load variant of that kernel */
       const int t = free_slot(x);
       HIP_TRY(wdpm_launch_fused(x->p.module, x->d_w[x->cur], x->d_w[t], x->d_dem, x->code, x->g, x->p.chunk_rows,
-                                x->signed_zero_safe ? 1 : 0, x->flush_pending ? &x->flush_thres : nullptr, x->d_scal, x->stream));
+                                x->signed_zero_safe ? 1 : 0, x->flush_pending ? &x->flush_thres : nullptr,
+                                x->drain_owed ? 1 : 0, x->d_scal, x->stream));
       x->cur = t;
       x->flush_pending = false;
+      x->drain_owed = x->p.module == WDPM_DRAIN;     /* this iteration's drain(): owed to the next launch or reader */
       x->launches += 1;
+      continue;
     } else {
       for (int oi = 1; oi <= 3; oi++)
         for (int oj = 1; oj <= 3; oj++)
@@ -526,13 +542,13 @@ int wdpm_iterate_overlapped(wdpm_ctx *x, int32_t n_iter, int32_t top_rows, int32
   HIP_TRY(hipEventRecord(x->ev_fork, x->stream));               /* w_in is complete here */
   if (t_last >= 0)
     HIP_TRY(wdpm_launch_fused_rows(x->p.module, w_in, w_out, x->d_dem, x->code, x->g, 0, t_last, x->p.chunk_rows, szs, flush,
-                                   x->d_scal, x->stream));
+                                   0, x->d_scal, x->stream));
   if (b_first < rows)
     HIP_TRY(wdpm_launch_fused_rows(x->p.module, w_in, w_out, x->d_dem, x->code, x->g, b_first - 2, rows - 1, x->p.chunk_rows,
-                                   szs, flush, x->d_scal, x->stream));
+                                   szs, flush, 0, x->d_scal, x->stream));
   HIP_TRY(hipStreamWaitEvent(x->side, x->ev_fork, 0));
   HIP_TRY(wdpm_launch_fused_rows(x->p.module, w_in, w_out, x->d_dem, x->code, x->g, t_last >= 0 ? t_last - 1 : 0,
-                                 b_first < rows ? b_first - 1 : rows - 1, x->p.chunk_rows, szs, flush, x->d_scal, x->side));
+                                 b_first < rows ? b_first - 1 : rows - 1, x->p.chunk_rows, szs, flush, 0, x->d_scal, x->side));
   if (x->timing) {
     HIP_TRY(hipEventRecord(ep.b, x->side));
     x->pending.push_back(ep);
@@ -560,7 +576,7 @@ int wdpm_max_diff(wdpm_ctx *x, int32_t row_lo, int32_t row_hi, double *out) {
 /* WDPMCL.c:1257-1268.  final_sum is the reference's sequential row-major sum (an ordinary parallel
  * sum would round differently): wdpm_volume_partial evaluates exactly that sum on the device. */
 int wdpm_drain_stats(wdpm_ctx *x, double *diffdrain, double *final_sum) {
-  if (bind(x)) return 1;
+  if (bind(x) || ensure_drained(x)) return 1;
   if (diffdrain) {
     HIP_TRY(hipMemcpyAsync(x->h_pin, x->d_scal, 2 * sizeof(double), hipMemcpyDeviceToHost, x->stream));
     HIP_TRY(hipStreamSynchronize(x->stream));

@@ -27,6 +27,8 @@ struct wdpm_ctx {
   int old;                      /* d_w[old] is oldwater (WDPMCL.c:1069-1073) - possibly still UNFLUSHED, see flush_pending */
   bool flush_pending;           /* wdpm_begin_block's threshold flush has not been applied yet: cur == old, and the next
                                    iteration launch applies it while loading (no pass over the raster of its own) */
+  bool drain_owed;              /* drain module: the last iteration's drain() (WDPMCL.c:1089) has not been applied to d_w[cur];
+                                   the next iteration launch does it as it loads, anybody else asks ensure_drained() first */
   double flush_thres;           /* the threshold of the current block: the flush still owed to d_w[cur] (flush_pending)
                                    and to the snapshot when wdpm_max_diff reads it; -inf = none */
   double *d_scal;               /* [0] totaldrain, [1] olddrain */

@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(256, WDPM_FUSED_MIN_WAVES)
 fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout,
                        const double *__restrict__ dem, const DemCode code, const SlabGeom g, const int nstrips,
                        const int nitems, const int H, const int A0, const int out_last,
-                       double *__restrict__ totaldrain, const double thres) {
+                       double *__restrict__ totaldrain, const double thres, const int drain_owed) {
   const int lane = threadIdx.x & 63;
   // Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2; placement is only a
   // speed matter, never correctness): give each XCD a contiguous run of work items so that the
@@ -283,6 +283,32 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
   DrainState ds;
   ds.td = MODULE == 2 ? *totaldrain : 0.0;
   ds.hit = false;
+  // exactly one wave holds the outlet cell in its exact output region; it sees every pass that touches
+  // the outlet, in the reference's order, so its totaldrain is the raster's
+  bool owner = false;
+  if (MODULE == 2) {
+    const int dcol_hi = oc_hi < g.ncp - 1 ? oc_hi : g.ncp - 1;
+    owner = g.dr >= or_lo && g.dr <= or_hi && g.dc >= oc_lo && g.dc <= dcol_hi;
+    // drain_owed: the previous iteration's drain() (WDPMCL.c:1089 -> :1859-1897) has not been applied to `win`
+    // yet - there is no launch of its own for it.  Its sum enters totaldrain here (row-major from 0.0, valid
+    // cells with water, :1877-1884), its zeroing of the nine cells (:1885-1889) happens as rows are loaded.
+    if (drain_owed && owner && g.dr >= 1 && g.dr <= g.rows - 2 && g.dc >= 1 && g.dc <= g.ncp - 2) {
+      double sum = 0.0;
+#pragma unroll
+      for (int i = -1; i <= 1; i++)
+#pragma unroll
+        for (int j = -1; j <= 1; j++) {
+          const size_t k = (size_t)(g.dr + i) * g.ncp + (g.dc + j);
+          const double wk = win[k];
+          if (dem[k] < WDPM_INF && wk > 0) sum += wk;
+        }
+      ds.td = ds.td + sum;
+    }
+  }
+  const bool owed_here = MODULE == 2 && drain_owed && g.dr >= 1 && g.dr <= g.rows - 2 && g.dc >= 1 && g.dc <= g.ncp - 2;
+  bool owed_col[3];
+#pragma unroll
+  for (int j = 0; j < 3; j++) owed_col[j] = owed_here && colb + j >= g.dc - 1 && colb + j <= g.dc + 1;
 
   double W[7][3], D[7][3];
 #pragma unroll
@@ -405,6 +431,14 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
           if (DEM32) D[4 + i][j] = dem32_decode(EDGE ? P.qe[i][j] : P.qi[i][j], code.k0, code.D, code.rD);
           else D[4 + i][j] = P.ND[i][j];
         }
+      if (MODULE == 2 && owed_here && A + 3 * n + 2 >= g.dr - 1 && A + 3 * n <= g.dr + 1) {   // wave-uniform, rare
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          const bool owed_row = A + 3 * n + i >= g.dr - 1 && A + 3 * n + i <= g.dr + 1;
+#pragma unroll
+          for (int j = 0; j < 3; j++) W[4 + i][j] = owed_row && owed_col[j] ? 0.0 : W[4 + i][j];
+        }
+      }
       if (EDGE) {
 #pragma unroll
         for (int i = 0; i < 3; i++) {
@@ -462,13 +496,7 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
   if (edge) march(std::true_type{});
   else march(std::false_type{});
 
-  if (MODULE == 2) {
-    // exactly one wave owns the outlet cell in its exact output region; it saw every pass that
-    // touches the outlet, in the reference's order, so its totaldrain is the raster's.
-    const int dcol_hi = oc_hi < g.ncp - 1 ? oc_hi : g.ncp - 1;
-    const bool owner = g.dr >= or_lo && g.dr <= or_hi && g.dc >= oc_lo && g.dc <= dcol_hi;
-    if (owner && lane == 0) *totaldrain = ds.td;
-  }
+  if (MODULE == 2 && owner && lane == 0) *totaldrain = ds.td;
 }
 
 __global__ void dpp_probe_kernel(int *out) {
@@ -546,15 +574,16 @@ static hipError_t dpp_selfcheck(hipStream_t s) {
 
 hipError_t wdpm_launch_fused(int module, const double *w_in, double *w_out, const double *dem, const DemCode &code,
                              const SlabGeom &g, int chunk_rows, int signed_zero_safe, const double *flush,
-                             double *totaldrain, hipStream_t s) {
+                             int drain_owed, double *totaldrain, hipStream_t s) {
   return wdpm_launch_fused_rows(module, w_in, w_out, dem, code, g, 0, g.rows - 1, chunk_rows, signed_zero_safe, flush,
-                                totaldrain, s);
+                                drain_owed, totaldrain, s);
 }
 
 /* one iteration restricted to the output rows [A0 + 2 (0 when A0 == 0), out_last]; A0 % 3 == 0 */
 hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out, const double *dem,
                                   const DemCode &code, const SlabGeom &g, int A0, int out_last, int chunk_rows,
-                                  int signed_zero_safe, const double *flush, double *totaldrain, hipStream_t s) {
+                                  int signed_zero_safe, const double *flush, int drain_owed, double *totaldrain,
+                                  hipStream_t s) {
   hipError_t e = dpp_selfcheck(s);
   if (e != hipSuccess) return e;
   if (A0 < 0 || A0 % 3 != 0 || out_last > g.rows - 1 || out_last < A0) return hipErrorInvalidValue;
@@ -604,7 +633,7 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
   if (nchunks < 1) nchunks = 1;
   const int nitems = nstrips * nchunks;
   const dim3 grid(((nitems + 3) / 4 + 7) / 8 * 8), block(256);   // multiple of 8: see the XCD remap
-#define WDPM_LAUNCH(...) hipLaunchKernelGGL((fused_iteration_kernel<__VA_ARGS__>), grid, block, 0, s, w_in, w_out, dem, code, g, nstrips, nitems, H, A0, out_last, totaldrain, thres)
+#define WDPM_LAUNCH(...) hipLaunchKernelGGL((fused_iteration_kernel<__VA_ARGS__>), grid, block, 0, s, w_in, w_out, dem, code, g, nstrips, nitems, H, A0, out_last, totaldrain, thres, module == 2 ? drain_owed : 0)
   if (module == 2 && fast) { if (flush) WDPM_LAUNCH(2, false, false, true); else WDPM_LAUNCH(2, false, false, false); }
   else if (module == 2) WDPM_LAUNCH(2, true, false, false);
   else if (dem32) { if (flush) WDPM_LAUNCH(0, false, true, true); else WDPM_LAUNCH(0, false, true, false); }

@@ -57,14 +57,17 @@ hipError_t wdpm_launch_pass(int module, double *w, const double *dem, const Slab
 /* one whole iteration (9 passes) fused in one launch: w_in -> w_out (distinct buffers) */
 /* signed_zero_safe = 0 selects the faster add/subtract variant that is exact when the water raster
  * holds no -0.0 (wdpm_stencil.h::flow_add_nz) */
-/* flush != nullptr: every water value is replaced by 0 when it is < *flush as it is loaded (the block's
+/* drain_owed (drain module): the previous iteration's drain() has not been applied to w_in; this launch does it
+ * (sum into totaldrain by the wave that owns the outlet, the nine cells read as 0).
+ * flush != nullptr: every water value is replaced by 0 when it is < *flush as it is loaded (the block's
  * threshold flush, WDPMCL.c:1055-1065, riding on the first iteration; only with signed_zero_safe == 0) */
 hipError_t wdpm_launch_fused(int module, const double *w_in, double *w_out, const double *dem, const DemCode &code,
                              const SlabGeom &g, int chunk_rows, int signed_zero_safe, const double *flush,
-                             double *totaldrain, hipStream_t s);
+                             int drain_owed, double *totaldrain, hipStream_t s);
 hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out, const double *dem,
                                   const DemCode &code, const SlabGeom &g, int A0, int out_last, int chunk_rows,
-                                  int signed_zero_safe, const double *flush, double *totaldrain, hipStream_t s);
+                                  int signed_zero_safe, const double *flush, int drain_owed, double *totaldrain,
+                                  hipStream_t s);
 /* *flag |= 1 if any of the n doubles at p is -0.0 */
 hipError_t wdpm_launch_scan_negzero(const double *p, size_t n, unsigned long long *flag, hipStream_t s);
 /* drain() (WDPMCL.c:1859-1897) on the device */
