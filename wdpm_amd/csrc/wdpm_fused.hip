@@ -499,6 +499,205 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
   if (MODULE == 2 && owner && lane == 0) *totaldrain = ds.td;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Small rasters: the "triangle" kernel.
+//
+// A raster of a few hundred rows cannot fill the chip, and the marching kernel above then runs at its
+// latency floor: every wave needs H/3 + 2 window steps of nine DEPENDENT 3x3 blocks each (one lane works
+// on one block at a time), about 10 us per launch on a 482 x 471 raster however many SIMDs idle.  Here a
+// wave takes NINE rows at once and produces the three middle ones in one go:
+//       oi = 1 on rows 0-2, 3-5, 6-8      three independent row blocks ...
+//       oi = 2 on rows 1-3, 4-6           ... two ...
+//       oi = 3 on rows 2-4                ... one: rows 2-4 have then seen all nine passes
+// Six stages instead of the marching kernel's nine for a 3-row chunk, and the row blocks of a stage are
+// advanced in LOCKSTEP - neighbour step k of block a, of block b, of block c, then step k+1 ... - so the
+// fp64 pipeline sees up to three independent dependency chains instead of one.
+// Same trapezoid, same pass order per cell, same arithmetic (stage_impl's blocks): bit-identical.
+// ---------------------------------------------------------------------------------------------
+/* NB independent 3x3 blocks of one colour pass, advanced in lockstep (non-outlet form; block b is
+ * w[b][row][col] with the centre at [1][1], neighbours in row-major order) */
+template <int MODULE, int NB>
+__device__ __forceinline__ void blocks_lockstep(double (&w)[NB][3][3], const double (&d)[NB][3][3]) {
+  double wc[NB], dce[NB];
+  bool gate[NB];
+#pragma unroll
+  for (int b = 0; b < NB; b++) {
+    wc[b] = w[b][1][1];
+    gate[b] = (wc[b] > 0.0) & (d[b][1][1] < WDPM_INF);             // WDPMCL.c:1099
+    dce[b] = gate[b] ? d[b][1][1] : -WDPM_INF;                      // see flow_add_nz / flow_drain_nz
+    if (MODULE == 2) wc[b] = gate[b] ? wc[b] : 0.0;
+  }
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const int r = 1 + nb_dr(k), c = 1 + nb_dc(k);
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+      if (MODULE == 2) flow_drain_nz(dce[b], wc[b], d[b][r][c], w[b][r][c]);
+      else flow_add_nz(dce[b], wc[b], d[b][r][c], w[b][r][c]);
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < NB; b++) w[b][1][1] = MODULE == 2 ? (gate[b] ? wc[b] : w[b][1][1]) : wc[b];
+}
+
+/* one row alignment (three column alignments oj = 1,2,3) on the NB row blocks at window slots
+ * S0 + 3b .. S0 + 3b + 2 of a window of NR rows; the lockstep twin of stage_impl */
+template <int MODULE, int NB, int S0, int NR>
+__device__ __forceinline__ void stage_lockstep(double (&W)[NR][3], const double (&D)[NR][3]) {
+  double w[NB][3][3], d[NB][3][3];
+  double n0[NB][3], n1[NB][3], e0[NB][3], e1[NB][3];      // columns 0 and 1 of the next lane: water, elevation
+  // oj = 1: own columns 0,1,2
+#pragma unroll
+  for (int b = 0; b < NB; b++)
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) { w[b][r][c] = W[S0 + 3 * b + r][c]; d[b][r][c] = D[S0 + 3 * b + r][c]; }
+  blocks_lockstep<MODULE, NB>(w, d);
+  // oj = 2: own columns 1,2 + column 0 of the next lane
+#pragma unroll
+  for (int b = 0; b < NB; b++)
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      n0[b][r] = lane_next(w[b][r][0]);
+      e0[b][r] = lane_next(d[b][r][0]);
+      W[S0 + 3 * b + r][0] = w[b][r][0];                  // column 0 is done for this row alignment (until handed back)
+      w[b][r][0] = w[b][r][1]; w[b][r][1] = w[b][r][2]; w[b][r][2] = n0[b][r];
+      d[b][r][0] = d[b][r][1]; d[b][r][1] = d[b][r][2]; d[b][r][2] = e0[b][r];
+    }
+  blocks_lockstep<MODULE, NB>(w, d);
+  // oj = 3: own column 2 + columns 0,1 of the next lane
+#pragma unroll
+  for (int b = 0; b < NB; b++)
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      n1[b][r] = lane_next(W[S0 + 3 * b + r][1] = w[b][r][0]);   // own column 1 as updated by oj = 1,2 ...
+      e1[b][r] = lane_next(D[S0 + 3 * b + r][1]);                // ... the next lane's is the one we borrow
+      w[b][r][0] = w[b][r][1]; w[b][r][1] = w[b][r][2]; w[b][r][2] = n1[b][r];
+      d[b][r][0] = d[b][r][1]; d[b][r][1] = d[b][r][2]; d[b][r][2] = e1[b][r];
+    }
+  blocks_lockstep<MODULE, NB>(w, d);
+  // own column 2 back into the window; the borrowed columns back to lane+1 (lane 0 keeps its own)
+#pragma unroll
+  for (int b = 0; b < NB; b++)
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      W[S0 + 3 * b + r][2] = w[b][r][0];
+      W[S0 + 3 * b + r][0] = lane_prev(w[b][r][1], W[S0 + 3 * b + r][0]);
+      W[S0 + 3 * b + r][1] = lane_prev(w[b][r][2], W[S0 + 3 * b + r][1]);
+    }
+}
+
+template <int MODULE, bool FLUSH>
+__global__ void __launch_bounds__(256, 2)
+tri_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout, const double *__restrict__ dem,
+                     const SlabGeom g, const int nstrips, const int nitems, const int A0, const int out_last,
+                     double *__restrict__ totaldrain, const double thres, const int drain_owed) {
+  const int lane = threadIdx.x & 63;
+  const int vb = (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8;       // XCD-contiguous items
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int item = vb * 4 + wave;
+  if (item >= nitems) return;                                               // wave-uniform
+  const int strip = item % nstrips, chunk = item / nstrips;
+  const int c0 = kStripOut * strip;
+  const int oc_lo = strip == 0 ? 0 : c0 + kHaloL;
+  int oc_hi = c0 + kStripIn - 1 - kHaloR;
+  if (oc_hi > g.ncp - 1) oc_hi = g.ncp - 1;
+  const int A = A0 + 3 * chunk;                   // window rows A .. A+8; exact output rows A+2 .. A+4
+  const int or_lo = A == 0 ? 0 : A + 2;
+  int or_hi = A + 4;
+  if (or_hi > out_last) or_hi = out_last;
+  const int colb = c0 + 3 * lane;
+  const size_t pitch = (size_t)g.ncp;
+
+  DrainState ds;
+  ds.td = MODULE == 2 ? *totaldrain : 0.0;
+  ds.hit = false;
+  bool owner = false;
+  const bool outlet_inside = g.dr >= 1 && g.dr <= g.rows - 2 && g.dc >= 1 && g.dc <= g.ncp - 2;
+  if (MODULE == 2) {
+    owner = g.dr >= or_lo && g.dr <= or_hi && g.dc >= oc_lo && g.dc <= oc_hi;
+    if (drain_owed && owner && outlet_inside) {                              // the previous iteration's drain(), see above
+      double sum = 0.0;
+#pragma unroll
+      for (int i = -1; i <= 1; i++)
+#pragma unroll
+        for (int j = -1; j <= 1; j++) {
+          const size_t k = (size_t)(g.dr + i) * g.ncp + (g.dc + j);
+          const double wk = win[k];
+          if (dem[k] < WDPM_INF && wk > 0) sum += wk;
+        }
+      ds.td = ds.td + sum;
+    }
+  }
+
+  // nine rows x three columns per lane; cells outside the slab: dem = +inf, water = 0
+  double W[9][3], D[9][3];
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    const int r = A + i;
+    const int rc = r < g.rows ? r : g.rows - 1;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const int c = colb + j;
+      const int cc = c < g.ncp ? c : g.ncp - 1;
+      const bool ok = (r < g.rows) & (c < g.ncp);
+      double wv = win[(size_t)rc * pitch + cc];
+      const double dv = dem[(size_t)rc * pitch + cc];
+      if (FLUSH) wv = wv < thres ? 0.0 : wv;                                 // WDPMCL.c:1059-1062
+      if (MODULE == 2 && drain_owed && outlet_inside)
+        wv = (r >= g.dr - 1 && r <= g.dr + 1 && c >= g.dc - 1 && c <= g.dc + 1) ? 0.0 : wv;   // :1885-1889
+      W[i][j] = ok ? wv : 0.0;
+      D[i][j] = ok ? dv : WDPM_INF;
+    }
+  }
+
+  if (MODULE == 2 && g.dr >= A && g.dr <= A + 8) {
+    // the outlet's row is in this window (a handful of waves): the marching kernel's stages with runoffd()'s
+    // outlet branch, one row block at a time.  Row blocks of one row alignment are disjoint, so at most one
+    // of them touches the outlet and totaldrain still accumulates in pass order.
+    bool cdr[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) cdr[j] = colb + j == g.dc;
+    double Wm[7][3], Dm[7][3];
+    auto run = [&](auto s0_tag, const int row_s0) {
+      constexpr int S0 = decltype(s0_tag)::value;
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) { Wm[r][j] = W[S0 + r][j]; Dm[r][j] = D[S0 + r][j]; }
+      stage_impl<2, false, 0, true>(Wm, Dm, row_s0, g.dr, cdr, ds);
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) W[S0 + r][j] = Wm[r][j];
+    };
+    run(std::integral_constant<int, 0>{}, A + 0);
+    run(std::integral_constant<int, 3>{}, A + 3);
+    run(std::integral_constant<int, 6>{}, A + 6);
+    run(std::integral_constant<int, 1>{}, A + 1);
+    run(std::integral_constant<int, 4>{}, A + 4);
+    run(std::integral_constant<int, 2>{}, A + 2);
+  } else {
+    stage_lockstep<MODULE, 3, 0, 9>(W, D);        // oi = 1 on rows 0-2, 3-5, 6-8
+    stage_lockstep<MODULE, 2, 1, 9>(W, D);        // oi = 2 on rows 1-3, 4-6
+    stage_lockstep<MODULE, 1, 2, 9>(W, D);        // oi = 3 on rows 2-4
+  }
+
+  // rows or_lo .. or_hi, columns oc_lo .. oc_hi (slots 0 and 1 only for the raster's first rows)
+#pragma unroll
+  for (int i = 0; i < 5; i++) {
+    const int r = A + i;
+    if (r < or_lo || r > or_hi) continue;                                    // wave-uniform
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const int c = colb + j;
+      if (c >= oc_lo && c <= oc_hi) __builtin_nontemporal_store(W[i][j], wout + (size_t)r * pitch + c);
+    }
+  }
+  if (MODULE == 2 && owner && lane == 0) *totaldrain = ds.td;
+}
+
 __global__ void dpp_probe_kernel(int *out) {
   const int lane = threadIdx.x;
   const double v = (double)lane;
@@ -589,6 +788,32 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
   if (A0 < 0 || A0 % 3 != 0 || out_last > g.rows - 1 || out_last < A0) return hipErrorInvalidValue;
   if (flush && signed_zero_safe) return hipErrorInvalidValue;   /* the caller flushes in place for that variant */
   const double thres = flush ? *flush : 0.0;
+  {
+    // Small launches: if every 3-row chunk of the window fits on the chip at once, the triangle kernel's six
+    // lockstep stages beat the marching kernel's nine dependent ones (482 x 471: DESIGN.md §4.1c).
+    // WDPM_TRI=0 keeps the marching kernel (A/B runs), WDPM_TRI=2 forces the triangle kernel on any size.
+    static int env_tri = -1, tri_slots = 0;
+    if (env_tri < 0) { const char *t = getenv("WDPM_TRI"); env_tri = t ? atoi(t) : 1; }
+    if (!tri_slots) {
+      int dev = 0, cus = 256, blocks = 1;
+      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, tri_iteration_kernel<0, false>, 256, 0) != hipSuccess || blocks < 1) blocks = 1;
+      tri_slots = cus * blocks * 4;
+    }
+    int nstr = 1;
+    if (g.ncp > kStripIn - kHaloR) nstr = (g.ncp - (kStripIn - kHaloR) + kStripOut - 1) / kStripOut + 1;
+    int nch = (out_last - A0 - 1 + 2) / 3;
+    if (nch < 1) nch = 1;
+    const long long items = (long long)nstr * nch;
+    if (env_tri && !signed_zero_safe && chunk_rows < 3 && (items <= tri_slots || env_tri == 2)) {
+      const dim3 tgrid(((unsigned)((items + 3) / 4) + 7) / 8 * 8), tblock(256);
+#define WDPM_TRI_LAUNCH(M, F) hipLaunchKernelGGL((tri_iteration_kernel<M, F>), tgrid, tblock, 0, s, w_in, w_out, dem, g, nstr, (int)items, A0, out_last, totaldrain, thres, module == 2 ? drain_owed : 0)
+      if (module == 2) { if (flush) WDPM_TRI_LAUNCH(2, true); else WDPM_TRI_LAUNCH(2, false); }
+      else { if (flush) WDPM_TRI_LAUNCH(0, true); else WDPM_TRI_LAUNCH(0, false); }
+#undef WDPM_TRI_LAUNCH
+      return hipGetLastError();
+    }
+  }
   int nstrips = 1;
   if (g.ncp > kStripIn - kHaloR) nstrips = (g.ncp - (kStripIn - kHaloR) + kStripOut - 1) / kStripOut + 1;
   const bool fast = !signed_zero_safe;
