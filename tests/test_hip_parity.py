@@ -515,3 +515,28 @@ def test_lazy_flush_and_snapshot_rotation(hip, oracle, module, kernel):
                 assert n_bit_diff(a, b) == 0, [op[0] for op in script]
             else:
                 assert a == b, ([op[0] for op in script], a, b)
+
+
+@pytest.mark.parametrize("chunk", [0, 6])
+def test_drain_outlet_at_every_window_position(hip, oracle, chunk):
+    """the outlet forced onto every row offset of a 9-row window and onto columns at every lane / strip
+    alignment (first and last lane of a strip, both sides of a strip boundary, the halo columns): water and
+    totaldrain after a few iterations, triangle kernel (chunk 0 on a raster this small) and marching kernel"""
+    R, C = 32, 400
+    dem, water, miss = random_case(77, R, C, missing_frac=0.02, dry_frac=0.1)
+    bd, bw = pad(dem, water, miss)
+    cols = [1, 2, 3, 4, 168, 170, 171, 172, 173, 178, 179, 180, 189, 190, 191, 192, 193, 340, 341, 342, 343, 399, 400]
+    for dr in list(range(1, 14)) + [R - 1, R]:
+        for dc in cols[(dr * 5) % 3::3]:
+            kw = dict(module="drain", nrows=R, ncols=C, missingvalue=miss, drainrow=dr, draincol=dc)
+            with hip.context(kernel=wdpm_amd.KERNEL_FUSED, chunk_rows=chunk, **kw) as g, oracle.context(**kw) as o:
+                for c in (g, o):
+                    c.upload(bd, bw)
+                    c.totaldrain = 0.125
+                    c.iterate(3)
+                assert g.totaldrain == o.totaldrain, (dr, dc)
+                assert n_bit_diff(g.download_water(), o.download_water()) == 0, (dr, dc)
+                for c in (g, o):
+                    c.begin_block(1e-3)
+                    c.iterate(2)
+                assert g.drain_stats() == o.drain_stats() and g.max_diff() == o.max_diff(), (dr, dc)

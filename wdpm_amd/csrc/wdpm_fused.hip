@@ -131,6 +131,42 @@ __device__ __forceinline__ void block_update(
     flow_drain(d11, wc, d20, w20, gate);
     flow_drain(d11, wc, d21, w21, gate);
     flow_drain(d11, wc, d22, w22, gate);
+  } else if (MODULE == 2 && !SZ_SAFE) {
+    // A block that may hold the outlet, no -0.0 in the raster: the plain neighbour step (flow_drain_nz) plus,
+    // for the ONE neighbour position that can be the outlet in this wave, runoffd()'s sink (:1980-1985).
+    // Which of the block's rows is the outlet's row is wave-uniform (rd*), whether ANY lane has the outlet's
+    // column at block column c takes a ballot (anyc*): the sink's few instructions sit behind a scalar branch
+    // that all but a handful of the raster's blocks never take.  After the sink the centre holds 0, and a
+    // centre without water moves nothing in the remaining steps (f = min(.., 0)), exactly as in the reference,
+    // whose loop also runs on with w[centre] = 0.
+    gate = gate & !(rd1 & cd1);                          // :1082 the outlet is never a centre
+    const double dce = gate ? d11 : -WDPM_INF;
+    wc = gate ? wc : 0.0;
+    const bool any0 = __ballot(cd0) != 0, any1 = __ballot(cd1) != 0, any2 = __ballot(cd2) != 0;
+    bool hit_any = false;
+    auto nb = [&](const double dn, double &wn, const bool rd, const bool anyc, const bool cd) {
+      if (rd & anyc) {                                   // wave-uniform
+        const bool hit = gate & cd & (dn < WDPM_INF);    // :1976,1980
+        const double td2 = (ds.td + wn) + wc;            // :1982
+        ds.td = hit ? td2 : ds.td;
+        wn = hit ? 0.0 : wn;                             // :1983
+        wc = hit ? 0.0 : wc;                             // :1984
+        hit_any = hit_any | hit;
+      }
+      flow_drain_nz(dce, wc, dn, wn);                    // :1988-2000
+    };
+    nb(d00, w00, rd0, any0, cd0);
+    nb(d01, w01, rd0, any1, cd1);
+    nb(d02, w02, rd0, any2, cd2);
+    nb(d10, w10, rd1, any0, cd0);
+    nb(d12, w12, rd1, any2, cd2);
+    nb(d20, w20, rd2, any0, cd0);
+    nb(d21, w21, rd2, any1, cd1);
+    nb(d22, w22, rd2, any2, cd2);
+    wc = gate ? wc : w11;
+    // at most one lane of the wave holds the outlet in this pass: make its totaldrain the wave's
+    const unsigned long long m = __ballot(hit_any);
+    if (m) ds.td = wave_read(ds.td, __ffsll((long long)m) - 1);
   } else if (MODULE == 2) {
     gate = gate & !(rd1 & cd1);                          // :1082 the outlet is never a centre
     ds.hit = false;
@@ -631,53 +667,130 @@ tri_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout, 
     }
   }
 
-  // nine rows x three columns per lane; cells outside the slab: dem = +inf, water = 0
+  // nine rows x three columns per lane; cells outside the slab: dem = +inf, water = 0.  Row bases are
+  // wave-uniform (scalar registers), the lane contributes a 32-bit byte offset: saddr-form loads, no 64-bit
+  // address arithmetic on the vector unit.  Only waves at the slab's right / lower edge mask anything.
+  const bool edge = (c0 + kStripIn > g.ncp) || (A + 9 > g.rows);                   // wave-uniform
+  unsigned voff[3];
+#pragma unroll
+  for (int j = 0; j < 3; j++) voff[j] = 8u * (unsigned)(colb + j < g.ncp ? colb + j : g.ncp - 1);
   double W[9][3], D[9][3];
 #pragma unroll
   for (int i = 0; i < 9; i++) {
-    const int r = A + i;
-    const int rc = r < g.rows ? r : g.rows - 1;
+    const int rc = A + i < g.rows ? A + i : g.rows - 1;
+    const char *bw = reinterpret_cast<const char *>(win + (size_t)rc * pitch);
+    const char *bd = reinterpret_cast<const char *>(dem + (size_t)rc * pitch);
 #pragma unroll
     for (int j = 0; j < 3; j++) {
-      const int c = colb + j;
-      const int cc = c < g.ncp ? c : g.ncp - 1;
-      const bool ok = (r < g.rows) & (c < g.ncp);
-      double wv = win[(size_t)rc * pitch + cc];
-      const double dv = dem[(size_t)rc * pitch + cc];
-      if (FLUSH) wv = wv < thres ? 0.0 : wv;                                 // WDPMCL.c:1059-1062
-      if (MODULE == 2 && drain_owed && outlet_inside)
-        wv = (r >= g.dr - 1 && r <= g.dr + 1 && c >= g.dc - 1 && c <= g.dc + 1) ? 0.0 : wv;   // :1885-1889
-      W[i][j] = ok ? wv : 0.0;
-      D[i][j] = ok ? dv : WDPM_INF;
+      W[i][j] = *reinterpret_cast<const double *>(bw + voff[j]);
+      D[i][j] = *reinterpret_cast<const double *>(bd + voff[j]);
     }
+  }
+  if (FLUSH) {
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) W[i][j] = W[i][j] < thres ? 0.0 : W[i][j];       // WDPMCL.c:1059-1062
+  }
+  if (MODULE == 2 && drain_owed && outlet_inside && A + 8 >= g.dr - 1 && A <= g.dr + 1) {   // wave-uniform, rare
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        const int r = A + i, c = colb + j;
+        W[i][j] = (r >= g.dr - 1 && r <= g.dr + 1 && c >= g.dc - 1 && c <= g.dc + 1) ? 0.0 : W[i][j];   // :1885-1889
+      }
+  }
+  if (edge) {
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        const bool ok = (A + i < g.rows) & (colb + j < g.ncp);
+        W[i][j] = ok ? W[i][j] : 0.0;
+        D[i][j] = ok ? D[i][j] : WDPM_INF;
+      }
   }
 
   if (MODULE == 2 && g.dr >= A && g.dr <= A + 8) {
-    // the outlet's row is in this window (a handful of waves): the marching kernel's stages with runoffd()'s
-    // outlet branch, one row block at a time.  Row blocks of one row alignment are disjoint, so at most one
-    // of them touches the outlet and totaldrain still accumulates in pass order.
+    // The outlet's row is in this window (a handful of waves).  In every row alignment at most ONE row block
+    // holds that row (row blocks of an alignment are disjoint, so totaldrain still accumulates in pass order):
+    // it runs the marching kernel's stage with runoffd()'s sink, the other blocks of the alignment stay in
+    // lockstep.  Which block it is is wave-uniform but only known at run time: the window is permuted with
+    // selects so that one copy of the code serves every position.
     bool cdr[5];
 #pragma unroll
     for (int j = 0; j < 5; j++) cdr[j] = colb + j == g.dc;
-    double Wm[7][3], Dm[7][3];
-    auto run = [&](auto s0_tag, const int row_s0) {
-      constexpr int S0 = decltype(s0_tag)::value;
+    const int off = g.dr - A;                                   // 0 .. 8
+    auto sel = [](const bool c, const double a, const double b) { return c ? a : b; };
+    double P[9][3], Q[9][3];
+    {  // oi = 1: row blocks at slots 0, 3, 6; the outlet's is block ob = off / 3
+      const int ob = off / 3;
 #pragma unroll
       for (int r = 0; r < 3; r++)
 #pragma unroll
-        for (int j = 0; j < 3; j++) { Wm[r][j] = W[S0 + r][j]; Dm[r][j] = D[S0 + r][j]; }
-      stage_impl<2, false, 0, true>(Wm, Dm, row_s0, g.dr, cdr, ds);
+        for (int j = 0; j < 3; j++) {
+          P[r][j] = sel(ob == 0, W[r][j], sel(ob == 1, W[3 + r][j], W[6 + r][j]));
+          Q[r][j] = sel(ob == 0, D[r][j], sel(ob == 1, D[3 + r][j], D[6 + r][j]));
+          P[3 + r][j] = sel(ob == 0, W[3 + r][j], W[r][j]);         Q[3 + r][j] = sel(ob == 0, D[3 + r][j], D[r][j]);
+          P[6 + r][j] = sel(ob == 2, W[3 + r][j], W[6 + r][j]);     Q[6 + r][j] = sel(ob == 2, D[3 + r][j], D[6 + r][j]);
+        }
+      double Wm[7][3], Dm[7][3];
 #pragma unroll
       for (int r = 0; r < 3; r++)
 #pragma unroll
-        for (int j = 0; j < 3; j++) W[S0 + r][j] = Wm[r][j];
-    };
-    run(std::integral_constant<int, 0>{}, A + 0);
-    run(std::integral_constant<int, 3>{}, A + 3);
-    run(std::integral_constant<int, 6>{}, A + 6);
-    run(std::integral_constant<int, 1>{}, A + 1);
-    run(std::integral_constant<int, 4>{}, A + 4);
-    run(std::integral_constant<int, 2>{}, A + 2);
+        for (int j = 0; j < 3; j++) { Wm[r][j] = P[r][j]; Dm[r][j] = Q[r][j]; }
+      stage_impl<2, false, 0, true>(Wm, Dm, A + 3 * ob, g.dr, cdr, ds);
+      stage_lockstep<2, 2, 3, 9>(P, Q);
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          const double o = Wm[r][j], x = P[3 + r][j], y = P[6 + r][j];   // outlet block, first other, second other
+          W[r][j] = sel(ob == 0, o, x);
+          W[3 + r][j] = sel(ob == 1, o, sel(ob == 0, x, y));
+          W[6 + r][j] = sel(ob == 2, o, y);
+        }
+    }
+    {  // oi = 2: row blocks at slots 1 and 4 (rows 1-3, 4-6); the outlet's row is in one of them for off = 1 .. 6
+      const int ob = off >= 1 && off <= 6 ? (off - 1) / 3 : -1;
+      if (ob < 0) {
+        stage_lockstep<2, 2, 1, 9>(W, D);
+      } else {
+        double Wm[7][3], Dm[7][3], Wo[3][3], Do[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+          for (int j = 0; j < 3; j++) {
+            Wm[r][j] = sel(ob == 0, W[1 + r][j], W[4 + r][j]);   Dm[r][j] = sel(ob == 0, D[1 + r][j], D[4 + r][j]);
+            Wo[r][j] = sel(ob == 0, W[4 + r][j], W[1 + r][j]);   Do[r][j] = sel(ob == 0, D[4 + r][j], D[1 + r][j]);
+          }
+        stage_impl<2, false, 0, true>(Wm, Dm, A + 1 + 3 * ob, g.dr, cdr, ds);
+        stage_lockstep<2, 1, 0, 3>(Wo, Do);
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+          for (int j = 0; j < 3; j++) {
+            W[1 + r][j] = sel(ob == 0, Wm[r][j], Wo[r][j]);
+            W[4 + r][j] = sel(ob == 0, Wo[r][j], Wm[r][j]);
+          }
+      }
+    }
+    // oi = 3: the one row block at slot 2 (rows 2-4)
+    if (off >= 2 && off <= 4) {
+      double Wm[7][3], Dm[7][3];
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) { Wm[r][j] = W[2 + r][j]; Dm[r][j] = D[2 + r][j]; }
+      stage_impl<2, false, 0, true>(Wm, Dm, A + 2, g.dr, cdr, ds);
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) W[2 + r][j] = Wm[r][j];
+    } else {
+      stage_lockstep<2, 1, 2, 9>(W, D);
+    }
   } else {
     stage_lockstep<MODULE, 3, 0, 9>(W, D);        // oi = 1 on rows 0-2, 3-5, 6-8
     stage_lockstep<MODULE, 2, 1, 9>(W, D);        // oi = 2 on rows 1-3, 4-6
