@@ -125,6 +125,32 @@ int wdpm_volume_partial(wdpm_ctx *ctx, int32_t row_lo, int32_t row_hi, double st
 /* convenience: begin_block + iterate(n_iter) + max_diff over the whole slab */
 int wdpm_run_block(wdpm_ctx *ctx, int32_t n_iter, double thres, double *max_diff);
 
+/* -- set-up and final statistics next to the rasters ---------------------------------
+ * What the reference does in host loops around the block loop, here on the device (CPU restatement: host
+ * loops).  A context holding a slab does its slab's share; wdpm_group_* below combines the shares. */
+typedef struct wdpm_setup {
+  int32_t op;             /* 0: water as given; 1: add (WDPMCL.c:727-740: wet cells += add, then cells <= 0 := add*rof);
+                             2: subtract (:879-885: max(water - sub, 0)); valid cells only */
+  double add, rof, sub;   /* metres, fraction, metres */
+} wdpm_setup;
+/* instead of wdpm_upload: the slab's padded rasters (border = missing / 0, WDPMCL.c:796-807) built from the
+ * UNPADDED file rasters (nrows x ncols of the whole raster; water may be NULL = zeros), the module's water
+ * adjustment applied on the way */
+int wdpm_upload_unpadded(wdpm_ctx *ctx, const double *dem, const double *water, const wdpm_setup *setup);
+/* over slab-local padded rows [row_lo,row_hi): cells with bigdem > missing (basincount, WDPMCL.c:643-650),
+ * those with water > 0.001 (:1397-1404), and max over ALL cells of (valid ? water : missing) decided by `>`
+ * from -inf (:1448-1457 after the masking of :1386-1391; the caller folds in the reference's seed cell) */
+int wdpm_count_stats(wdpm_ctx *ctx, int32_t row_lo, int32_t row_hi, int64_t *valid, int64_t *wet, double *maxv);
+/* the drain cell (WDPMCL.c:1005-1017) among rows [row_lo,row_hi): smallest bigdem > 0, first in row-major
+ * order; slab-local row (-1: no such cell) */
+int wdpm_find_drain(wdpm_ctx *ctx, int32_t row_lo, int32_t row_hi, double *mindem, int32_t *row, int32_t *col);
+/* a drain context created before the drain cell was known (drainrow < 0) learns it; whole-raster coordinates */
+int wdpm_set_drain(wdpm_ctx *ctx, int32_t drainrow, int32_t draincol);
+int wdpm_get_cell(wdpm_ctx *ctx, int32_t row, int32_t col, double *water, double *dem);   /* slab-local row */
+/* rows [file_row, file_row+nrows) of the FILE raster (they must lie in the slab), un-padded, NODATA cells as
+ * missingvalue when mask_missing (WDPMCL.c:1379-1392; scratch :1336-1344) */
+int wdpm_download_unpadded(wdpm_ctx *ctx, int32_t file_row, int32_t nrows, int32_t mask_missing, double *dst);
+
 /* -- plumbing for multi-GPU drivers (product library; the oracle returns host pointers) ------ */
 /* device pointer of the CURRENT water raster (changes after every wdpm_iterate/wdpm_pass) */
 int wdpm_water_ptr(wdpm_ctx *ctx, void **ptr);
@@ -245,6 +271,17 @@ int  wdpm_group_set_totaldrain(wdpm_group *grp, double v);
 int  wdpm_group_get_totaldrain(wdpm_group *grp, double *v);
 int  wdpm_group_run_block(wdpm_group *grp, int32_t n_iter, double thres, double *max_diff);
 int  wdpm_group_drain_stats(wdpm_group *grp, double *diffdrain, double *final_sum);
+/* set-up and final statistics over the whole raster (see wdpm_upload_unpadded etc.):
+ * upload_unpadded replaces wdpm_group_upload; find_drain returns whole-raster padded coordinates;
+ * set_drain returns 2 (and changes nothing) when the outlet lies too close to a slab boundary of the current
+ * partition - the caller then creates the group again with the now known drain cell;
+ * count_stats: maxv still wants the reference's seed folded in (water[0][0] of the masked file raster) */
+int  wdpm_group_upload_unpadded(wdpm_group *grp, const double *dem, const double *water, const wdpm_setup *setup);
+int  wdpm_group_count_stats(wdpm_group *grp, int64_t *valid, int64_t *wet, double *maxv);
+int  wdpm_group_find_drain(wdpm_group *grp, double *mindem, int32_t *drainrow, int32_t *draincol);
+int  wdpm_group_set_drain(wdpm_group *grp, int32_t drainrow, int32_t draincol);
+int  wdpm_group_get_cell(wdpm_group *grp, int32_t row, int32_t col, double *water, double *dem);
+int  wdpm_group_download_unpadded(wdpm_group *grp, int32_t mask_missing, double *water);
 /* host time the group's threads spent since creation queueing iteration launches and, separately, in halo
  * refreshes (both summed over ranks, seconds; the launch calls block when the device's queue is full, the
  * peer transport's refresh includes waiting for the other threads), and the iterations ONE rank queued */

@@ -190,11 +190,12 @@ def test_hip_cli_lossless_checkpoint_resume(workdir, golden):
     lossless_resume(HIP_CLI, golden, workdir)
 
 
-def test_cli_threaded_host_passes(workdir, golden):
-    """the set-up / statistics / ArcASCII passes of big rasters run on several host threads; forced on for
-    basin5 (WDPM_HOST_PAR_MIN=1): the golden add run stays the reference's, and one block of every module
-    gives the same report and the same bytes with and without threads"""
-    env = dict(os.environ, WDPM_HOST_PAR_MIN="1", WDPM_IO_THREADS="5")
+def test_cli_set_up_and_statistics_across_slabs(workdir, golden):
+    """set-up (module water, padding, basin count, drain-cell search, volumes) and the final statistics are done
+    by the back-end next to the rasters, slab by slab when the raster is spread over several contexts, and the
+    ArcASCII text is parsed / formatted on several host threads: the golden add run stays the reference's, and
+    one block of every module gives the same report and the same bytes on three slabs + five I/O threads as on one"""
+    env = dict(os.environ, WDPM_IO_THREADS="5", WDPM_DEVICES="0,0,0", WDPM_EXCHANGE_EVERY="2")
     g = golden["cfg2_add300_k1000"]
     p = subprocess.run([ORACLE_CLI] + g["args"], cwd=workdir, capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, p.stderr

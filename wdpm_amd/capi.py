@@ -44,6 +44,11 @@ class SlabStruct(C.Structure):
                 ("up", C.c_int32), ("down", C.c_int32)]
 
 
+class SetupStruct(C.Structure):
+    """struct wdpm_setup"""
+    _fields_ = [("op", C.c_int32), ("add", C.c_double), ("rof", C.c_double), ("sub", C.c_double)]
+
+
 class HaloOp(C.Structure):
     """struct wdpm_halo_op"""
     _fields_ = [("peer", C.c_int32), ("row", C.c_int32), ("nrows", C.c_int32)]
@@ -119,6 +124,18 @@ SYMBOLS = {
     "wdpm_rank_run_block": (C.c_int, [_vp, C.c_int32, C.c_double, _dp]),
     "wdpm_rank_drain_stats": (C.c_int, [_vp, _dp, _dp]),
     "wdpm_rank_download_owned": (C.c_int, [_vp, _vp]),
+    "wdpm_upload_unpadded": (C.c_int, [_vp, _vp, _vp, C.POINTER(SetupStruct)]),
+    "wdpm_count_stats": (C.c_int, [_vp, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _dp]),
+    "wdpm_find_drain": (C.c_int, [_vp, C.c_int32, C.c_int32, _dp, _ip, _ip]),
+    "wdpm_set_drain": (C.c_int, [_vp, C.c_int32, C.c_int32]),
+    "wdpm_get_cell": (C.c_int, [_vp, C.c_int32, C.c_int32, _dp, _dp]),
+    "wdpm_download_unpadded": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, _vp]),
+    "wdpm_group_upload_unpadded": (C.c_int, [_vp, _vp, _vp, C.POINTER(SetupStruct)]),
+    "wdpm_group_count_stats": (C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _dp]),
+    "wdpm_group_find_drain": (C.c_int, [_vp, _dp, _ip, _ip]),
+    "wdpm_group_set_drain": (C.c_int, [_vp, C.c_int32, C.c_int32]),
+    "wdpm_group_get_cell": (C.c_int, [_vp, C.c_int32, C.c_int32, _dp, _dp]),
+    "wdpm_group_download_unpadded": (C.c_int, [_vp, C.c_int32, _vp]),
     "wdpm_group_halo": (C.c_int, [_vp]),
     "wdpm_group_rank": (_vp, [_vp, C.c_int32]),
     "wdpm_group_enqueue_stats": (C.c_int, [_vp, _dp, _dp, C.POINTER(C.c_int64)]),

@@ -156,7 +156,7 @@ int wdpm_create(wdpm_ctx **out, const wdpm_params *p) {
   x->flush_pending = false;
   x->drain_owed = false;
   x->flush_thres = -__builtin_inf();
-  x->d_scal = nullptr; x->d_bits = nullptr; x->h_pin = nullptr;
+  x->d_scal = nullptr; x->d_bits = nullptr; x->h_pin = nullptr; x->d_stat = nullptr;
   x->d_dem32 = nullptr; x->code = DemCode{nullptr, 0.0, 1.0, 1.0, 0}; x->dem32_encodable = false;
   x->d_sum_approx = nullptr; x->d_sum_i = nullptr; x->d_sum_k = nullptr; x->d_sum_flag = nullptr;
   x->own_stream = true;
@@ -204,7 +204,7 @@ void wdpm_destroy(wdpm_ctx *x) {
   for (auto &ep : x->pending) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
   for (auto &ep : x->pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
   (void)hipFree(x->d_dem); (void)hipFree(x->d_w[0]); (void)hipFree(x->d_w[1]); (void)hipFree(x->d_w[2]);
-  (void)hipFree(x->d_scal); (void)hipFree(x->d_bits); (void)hipFree(x->d_dem32);
+  (void)hipFree(x->d_scal); (void)hipFree(x->d_bits); (void)hipFree(x->d_dem32); (void)hipFree(x->d_stat);
   if (x->h_pin) (void)hipHostFree(x->h_pin);
   (void)hipFree(x->d_sum_approx); (void)hipFree(x->d_sum_i); (void)hipFree(x->d_sum_k); (void)hipFree(x->d_sum_flag);
   if (x->own_stream && x->stream) (void)hipStreamDestroy(x->stream);
@@ -283,6 +283,101 @@ int wdpm_upload(wdpm_ctx *x, const double *bigdem, const double *bigwater) {
   x->signed_zero_safe = false;
   if (note_negzero(x, 0, x->g.rows)) return 1;
   if (encode_dem(x)) return 1;
+  return 0;
+}
+
+/* Set-up on the device: the slab's padded rasters straight from the UNPADDED file rasters.
+ * The two water rasters that are not current serve as staging for the host-to-device copies. */
+int wdpm_upload_unpadded(wdpm_ctx *x, const double *dem, const double *water, const wdpm_setup *su) {
+  if (!dem || !su) return fail("wdpm_upload_unpadded: null argument");
+  if (su->op < 0 || su->op > 2) return fail("wdpm_upload_unpadded: bad water operation %d", su->op);
+  if (bind(x)) return 1;
+  if (ensure_fresh_slot(x)) return 1;
+  const int a = (x->cur + 1) % 3, b = (x->cur + 2) % 3;
+  const int R = x->g.R, C = x->g.C;
+  int f0 = x->g.row0 - 1, f1 = x->g.row0 + x->g.rows - 2;     /* file rows behind the slab's padded rows */
+  const int first = f0 < 0 ? 0 : f0, last = f1 > R - 1 ? R - 1 : f1;
+  if (last >= first) {
+    const size_t off = (size_t)(first - f0) * C, n = (size_t)(last - first + 1) * C;
+    HIP_TRY(hipMemcpyAsync(x->d_w[a] + off, dem + (size_t)first * C, n * sizeof(double), hipMemcpyHostToDevice, x->stream));
+    if (water)
+      HIP_TRY(hipMemcpyAsync(x->d_w[b] + off, water + (size_t)first * C, n * sizeof(double), hipMemcpyHostToDevice, x->stream));
+  }
+  HIP_TRY(wdpm_launch_pad_setup(x->d_w[a], water ? x->d_w[b] : nullptr, x->d_dem, x->d_w[x->cur], x->g, su->op, su->add,
+                                su->rof, su->sub, x->stream));
+  /* the snapshot before any block is all zeros (as after wdpm_create) */
+  x->old = a;
+  x->flush_thres = -__builtin_inf();
+  HIP_TRY(hipMemsetAsync(x->d_w[a], 0, x->cells * sizeof(double), x->stream));
+  x->signed_zero_safe = false;
+  if (note_negzero(x, 0, x->g.rows)) return 1;
+  return encode_dem(x);
+}
+
+int wdpm_set_drain(wdpm_ctx *x, int32_t drainrow, int32_t draincol) {
+  if (x->p.module != WDPM_DRAIN) return fail("wdpm_set_drain: not a drain context");
+  if (bind(x) || ensure_drained(x)) return 1;
+  x->p.drainrow = drainrow;
+  x->p.draincol = draincol;
+  x->g.dr = drainrow - x->p.slab_row0;
+  x->g.dc = draincol;
+  return 0;
+}
+
+int wdpm_count_stats(wdpm_ctx *x, int32_t row_lo, int32_t row_hi, int64_t *valid, int64_t *wet, double *maxv) {
+  if (row_lo < 0 || row_hi > x->g.rows || row_lo > row_hi) return fail("wdpm_count_stats: bad row range");
+  if (bind(x) || ensure_flushed(x)) return 1;
+  if (!x->d_stat) HIP_TRY(hipMalloc(&x->d_stat, 4 * sizeof(unsigned long long)));
+  HIP_TRY(wdpm_launch_count_stats(x->d_w[x->cur], x->d_dem, (size_t)row_lo * x->g.ncp, (size_t)row_hi * x->g.ncp, x->g.miss,
+                                  x->d_stat, x->stream));
+  HIP_TRY(hipMemcpyAsync(x->h_pin, x->d_stat, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, x->stream));
+  HIP_TRY(hipStreamSynchronize(x->stream));
+  unsigned long long v[3];
+  memcpy(v, x->h_pin, sizeof v);
+  if (valid) *valid = (int64_t)v[0];
+  if (wet) *wet = (int64_t)v[1];
+  if (maxv) *maxv = v[2] ? wdpm_dem_key_to_double(v[2]) : -__builtin_inf();
+  return 0;
+}
+
+int wdpm_find_drain(wdpm_ctx *x, int32_t row_lo, int32_t row_hi, double *mindem, int32_t *row, int32_t *col) {
+  if (row_lo < 0 || row_hi > x->g.rows || row_lo > row_hi || !mindem || !row || !col) return fail("wdpm_find_drain: bad argument");
+  if (bind(x)) return 1;
+  if (!x->d_stat) HIP_TRY(hipMalloc(&x->d_stat, 4 * sizeof(unsigned long long)));
+  HIP_TRY(wdpm_launch_find_drain(x->d_dem, (size_t)row_lo * x->g.ncp, (size_t)row_hi * x->g.ncp, x->d_stat, x->stream));
+  HIP_TRY(hipMemcpyAsync(x->h_pin, x->d_stat, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, x->stream));
+  HIP_TRY(hipStreamSynchronize(x->stream));
+  unsigned long long v[2];
+  memcpy(v, x->h_pin, sizeof v);
+  if (v[0] == ~0ull || v[1] == ~0ull) { *row = -1; *col = -1; *mindem = __builtin_inf(); return 0; }
+  *mindem = wdpm_dem_key_to_double(v[0]);
+  *row = (int32_t)(v[1] / x->g.ncp);
+  *col = (int32_t)(v[1] % x->g.ncp);
+  return 0;
+}
+
+int wdpm_get_cell(wdpm_ctx *x, int32_t row, int32_t col, double *water, double *dem) {
+  if (row < 0 || row >= x->g.rows || col < 0 || col >= x->g.ncp) return fail("wdpm_get_cell: cell outside the slab");
+  if (bind(x) || ensure_flushed(x)) return 1;
+  const size_t k = (size_t)row * x->g.ncp + col;
+  HIP_TRY(hipMemcpyAsync(x->h_pin, x->d_w[x->cur] + k, sizeof(double), hipMemcpyDeviceToHost, x->stream));
+  HIP_TRY(hipMemcpyAsync(x->h_pin + 1, x->d_dem + k, sizeof(double), hipMemcpyDeviceToHost, x->stream));
+  HIP_TRY(hipStreamSynchronize(x->stream));
+  if (water) *water = x->h_pin[0];
+  if (dem) *dem = x->h_pin[1] < __builtin_inf() ? x->h_pin[1] : x->g.miss;     /* the device marks NODATA as +inf */
+  return 0;
+}
+
+int wdpm_download_unpadded(wdpm_ctx *x, int32_t file_row, int32_t nrows, int32_t mask_missing, double *dst) {
+  const int p0 = file_row + 1 - x->g.row0;                      /* slab-local padded row of the first file row */
+  if (nrows < 0 || file_row < 0 || file_row + nrows > x->g.R || p0 < 0 || p0 + nrows > x->g.rows || !dst)
+    return fail("wdpm_download_unpadded: rows outside the slab");
+  if (nrows == 0) return 0;
+  if (bind(x) || ensure_flushed(x)) return 1;
+  double *stage = x->d_w[free_slot(x)];
+  HIP_TRY(wdpm_launch_unpad(x->d_w[x->cur], x->d_dem, x->g, file_row, nrows, mask_missing, stage, x->stream));
+  HIP_TRY(hipMemcpyAsync(dst, stage, (size_t)nrows * x->g.C * sizeof(double), hipMemcpyDeviceToHost, x->stream));
+  HIP_TRY(hipStreamSynchronize(x->stream));
   return 0;
 }
 

@@ -34,6 +34,7 @@ struct wdpm_ctx {
   double *d_scal;               /* [0] totaldrain, [1] olddrain */
   unsigned long long *d_bits;   /* max-diff reduction cell */
   double *h_pin;                /* pinned staging: 4 doubles */
+  unsigned long long *d_stat;   /* wdpm_count_stats / wdpm_find_drain: 4 reduction cells */
   double *d_sum_approx;         /* wdpm_volume_partial: per-chunk approximate sums, integer sums, binades, flags */
   long long *d_sum_i;
   int *d_sum_k;

@@ -80,4 +80,14 @@ hipError_t wdpm_launch_flush_snapshot(double *w, double *old, size_t cells, doub
 hipError_t wdpm_launch_max_diff(const double *w, const double *old, double old_thres, const double *dem, const SlabGeom &g,
                                 int row_lo, int row_hi, unsigned long long *result_bits, hipStream_t s);
 
+/* set-up and final statistics on the device, see wdpm_kernels.hip */
+hipError_t wdpm_launch_pad_setup(const double *fdem, const double *fwater, double *dem, double *w, const SlabGeom &g,
+                                 int op, double add, double rof, double sub, hipStream_t s);
+hipError_t wdpm_launch_count_stats(const double *w, const double *dem, size_t first, size_t last, double miss,
+                                   unsigned long long *out3, hipStream_t s);
+hipError_t wdpm_launch_find_drain(const double *dem, size_t first, size_t last, unsigned long long *key_and_index,
+                                  hipStream_t s);
+hipError_t wdpm_launch_unpad(const double *w, const double *dem, const SlabGeom &g, int frow, int nrows, int mask,
+                             double *out, hipStream_t s);
+
 #endif

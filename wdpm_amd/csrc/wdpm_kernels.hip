@@ -366,3 +366,159 @@ hipError_t wdpm_launch_max_diff(const double *w, const double *old, double old_t
                      row_lo == 0 ? 1 : 0, result_bits);
   return hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------
+// Set-up and final statistics on the device: what the reference does in host loops
+// around the block loop (WDPMCL.c:643-650, :727-740, :796-807, :879-885, :1005-1017, :1379-1459).
+// ---------------------------------------------------------------------------------------------
+/* padded slab rows [0, rows) from the UNPADDED file rasters: border = (+inf for NODATA, 0) (:796-807), the
+ * module's water adjustment on valid cells (add :727-740, subtract :879-885); fdem / fwater point at file row
+ * (row0 - 1) of the staged file rasters (fwater may be null: zeros) */
+__global__ void __launch_bounds__(256)
+pad_setup_kernel(const double *__restrict__ fdem, const double *__restrict__ fwater, double *__restrict__ dem,
+                 double *__restrict__ w, SlabGeom g, int op, double add, double rof, double sub) {
+  const size_t n = (size_t)g.rows * g.ncp, stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int r = (int)(i / g.ncp), c = (int)(i % g.ncp), gr = r + g.row0;     // padded coordinates
+    double d = __builtin_inf(), v = 0.0;
+    if (gr >= 1 && gr <= g.R && c >= 1 && c <= g.C) {
+      const size_t k = (size_t)r * g.C + (c - 1);        // fdem already starts at file row row0 - 1
+      d = fdem[k];
+      v = fwater ? fwater[k] : 0.0;
+      if (d > g.miss) {
+        if (op == 1) {                                   // :727-740: wet cells += add, then cells <= 0 = add * rof
+          if (v > 0) v += add;
+          if (v <= 0) v = add * rof;
+        } else if (op == 2) {                            // :879-885
+          const double t = v - sub;
+          v = t > 0 ? t : 0;
+        }
+      } else {
+        d = __builtin_inf();
+      }
+    }
+    dem[i] = d;
+    w[i] = v;
+  }
+}
+
+hipError_t wdpm_launch_pad_setup(const double *fdem, const double *fwater, double *dem, double *w, const SlabGeom &g,
+                                 int op, double add, double rof, double sub, hipStream_t s) {
+  size_t blocks = ((size_t)g.rows * g.ncp + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(pad_setup_kernel, dim3((unsigned)blocks), dim3(256), 0, s, fdem, fwater, dem, w, g, op, add, rof, sub);
+  return hipGetLastError();
+}
+
+/* out[0] += valid cells, out[1] += valid cells with water > 0.001 (:1397-1404), out[2] = max over cells of
+ * (valid ? water : miss) as an ordered key (:1448-1457 after the masking of :1386-1391; `>` from -inf) */
+__global__ void __launch_bounds__(256)
+count_stats_kernel(const double *__restrict__ w, const double *__restrict__ dem, size_t first, size_t last, double miss,
+                   unsigned long long *out) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  unsigned long long nv = 0, nw = 0;
+  double m = -__builtin_inf();
+  for (size_t i = first + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < last; i += stride) {
+    const bool ok = cell_valid(dem[i]);
+    const double v = ok ? w[i] : miss;
+    nv += ok;
+    nw += ok && v > 0.001;
+    if (v > m) m = v;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    nv += __shfl_xor(nv, off, 64);
+    nw += __shfl_xor(nw, off, 64);
+    const double o = __shfl_xor(m, off, 64);
+    if (o > m) m = o;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&out[0], nv);
+    atomicAdd(&out[1], nw);
+    atomicMax(&out[2], ordered_key(m));
+  }
+}
+
+hipError_t wdpm_launch_count_stats(const double *w, const double *dem, size_t first, size_t last, double miss,
+                                   unsigned long long *out3, hipStream_t s) {
+  hipError_t e = hipMemsetAsync(out3, 0, 3 * sizeof(unsigned long long), s);   /* key 0 sorts below every double */
+  if (e != hipSuccess || last <= first) return e;
+  size_t blocks = (last - first + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(count_stats_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w, dem, first, last, miss, out3);
+  return hipGetLastError();
+}
+
+/* drain-cell search (:1005-1017): the smallest dem > 0 and, among the cells that hold it, the first in
+ * row-major order: pass 1 the value, pass 2 the index */
+__global__ void __launch_bounds__(256)
+drain_min_kernel(const double *__restrict__ dem, size_t first, size_t last, unsigned long long *key) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  unsigned long long m = ~0ull;
+  for (size_t i = first + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < last; i += stride) {
+    const double v = dem[i];
+    if (v > 0 && v < 100000000.0) {          // :1007,1011 (NODATA is +inf here; a NODATA value >= 0 is the caller's case)
+      const unsigned long long kx = ordered_key(v);
+      m = kx < m ? kx : m;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const unsigned long long o = __shfl_xor(m, off, 64);
+    m = o < m ? o : m;
+  }
+  if ((threadIdx.x & 63) == 0 && m != ~0ull) atomicMin(key, m);
+}
+
+__global__ void __launch_bounds__(256)
+drain_first_kernel(const double *__restrict__ dem, size_t first, size_t last, const unsigned long long *key,
+                   unsigned long long *index) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const unsigned long long want = *key;
+  unsigned long long m = ~0ull;
+  for (size_t i = first + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < last; i += stride) {
+    const double v = dem[i];
+    if (v > 0 && ordered_key(v) == want) m = i < m ? i : m;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const unsigned long long o = __shfl_xor(m, off, 64);
+    m = o < m ? o : m;
+  }
+  if ((threadIdx.x & 63) == 0 && m != ~0ull) atomicMin(index, m);
+}
+
+hipError_t wdpm_launch_find_drain(const double *dem, size_t first, size_t last, unsigned long long *key_and_index,
+                                  hipStream_t s) {
+  hipError_t e = hipMemsetAsync(key_and_index, 0xff, 2 * sizeof(unsigned long long), s);
+  if (e != hipSuccess || last <= first) return e;
+  size_t blocks = (last - first + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(drain_min_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dem, first, last, key_and_index);
+  hipLaunchKernelGGL(drain_first_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dem, first, last, key_and_index,
+                     key_and_index + 1);
+  return hipGetLastError();
+}
+
+/* the un-padded raster of file rows [frow, frow + nrows): out[(r - frow) * C + c] = water, or miss on NODATA
+ * cells when mask is set (:1379-1392, the scratch variants :1336-1344) */
+__global__ void __launch_bounds__(256)
+unpad_kernel(const double *__restrict__ w, const double *__restrict__ dem, SlabGeom g, int frow, int nrows, int mask,
+             double *__restrict__ out) {
+  const size_t n = (size_t)nrows * g.C, stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int r = (int)(i / g.C), c = (int)(i % g.C);
+    const size_t k = (size_t)(frow + r + 1 - g.row0) * g.ncp + (c + 1);
+    const double v = w[k];
+    out[i] = mask && !cell_valid(dem[k]) ? g.miss : v;
+  }
+}
+
+hipError_t wdpm_launch_unpad(const double *w, const double *dem, const SlabGeom &g, int frow, int nrows, int mask,
+                             double *out, hipStream_t s) {
+  if (nrows <= 0) return hipSuccess;
+  size_t blocks = ((size_t)nrows * g.C + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(unpad_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w, dem, g, frow, nrows, mask, out);
+  return hipGetLastError();
+}

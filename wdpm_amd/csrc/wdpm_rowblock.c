@@ -107,10 +107,12 @@ struct wdpm_group {
   /* arguments of the current command */
   const double *a_dem, *a_water;
   double *a_out;
-  int a_iter, a_want_diff, a_want_sum;
+  int a_iter, a_want_diff, a_want_sum, a_mask, a_row, a_col;
   double a_thres, a_value;
+  const wdpm_setup *a_setup;
   /* results, one per rank (all ranks agree on the collective ones; rank 0's is returned) */
-  double res_a[MAXR], res_b[MAXR];
+  double res_a[MAXR], res_b[MAXR], res_c[MAXR];
+  int64_t res_i[MAXR], res_j[MAXR];
   /* barrier + scalar exchange between the rank threads */
   int bar_count;
   unsigned bar_gen;
@@ -434,8 +436,100 @@ int wdpm_rank_download_owned(wdpm_rank *r, double *dst) {
   return wdpm_download_rows(r->c, me->own_lo - me->row0, me->own_hi - me->own_lo + 1, dst);
 }
 
+/* ---- set-up and final statistics across ranks ---------------------------------- */
+static void owned_rows(const wdpm_rank *r, int *lo, int *hi) {     /* slab-local [lo, hi) */
+  const wdpm_slab *me = &r->s[r->rank];
+  *lo = r->n > 1 ? me->own_lo - me->row0 : 0;
+  *hi = r->n > 1 ? me->own_hi - me->row0 + 1 : r->p.nrows + 2;
+}
+
+static int rank_upload_unpadded(wdpm_rank *r, const double *dem, const double *water, const wdpm_setup *su) {
+  if (wdpm_upload_unpadded(r->c, dem, water, su)) return 1;
+  r->since = 0;
+  return agree_on_options(r);
+}
+
+static int rank_count_stats(wdpm_rank *r, int64_t *valid, int64_t *wet, double *maxv) {
+  int lo, hi;
+  owned_rows(r, &lo, &hi);
+  int64_t nv = 0, nw = 0;
+  double m = 0.0;
+  if (wdpm_count_stats(r->c, lo, hi, &nv, &nw, &m)) return 1;
+  double mine[3] = {(double)nv, (double)nw, m}, all[MAXR * 3];      /* counts < 2^53: exact in a double */
+  if (rank_allgather(r, mine, 3, all)) return 1;
+  nv = nw = 0;
+  m = all[2];
+  for (int q = 0; q < r->n; q++) {
+    nv += (int64_t)all[3 * q];
+    nw += (int64_t)all[3 * q + 1];
+    if (all[3 * q + 2] > m) m = all[3 * q + 2];
+  }
+  if (valid) *valid = nv;
+  if (wet) *wet = nw;
+  if (maxv) *maxv = m;
+  return 0;
+}
+
+/* WDPMCL.c:1005-1017 over the whole raster: the smallest value wins, among equal values the lowest rank
+ * (= the first rows), within a rank the first cell in row-major order */
+static int rank_find_drain(wdpm_rank *r, double *mindem, int32_t *drainrow, int32_t *draincol) {
+  int lo, hi;
+  owned_rows(r, &lo, &hi);
+  double md = 0.0;
+  int32_t row = -1, col = -1;
+  if (wdpm_find_drain(r->c, lo, hi, &md, &row, &col)) return 1;
+  const wdpm_slab *me = &r->s[r->rank];
+  double mine[3] = {md, row < 0 ? -1.0 : (double)(row + (r->n > 1 ? me->row0 : 0)), (double)col}, all[MAXR * 3];
+  if (rank_allgather(r, mine, 3, all)) return 1;
+  int best = -1;
+  for (int q = 0; q < r->n; q++)
+    if (all[3 * q + 1] >= 0 && (best < 0 || all[3 * q] < all[3 * best])) best = q;
+  if (best < 0) { *mindem = 0.0; *drainrow = 0; *draincol = 0; return 0; }   /* no cell with dem > 0: the reference keeps 0,0 */
+  *mindem = all[3 * best];
+  *drainrow = (int32_t)all[3 * best + 1];
+  *draincol = (int32_t)all[3 * best + 2];
+  return 0;
+}
+
+/* 0: set; 2: the outlet is closer than three rows to a boundary of this partition (nothing changed) */
+static int rank_set_drain(wdpm_rank *r, int32_t drainrow, int32_t draincol) {
+  for (int i = 1; i < r->n; i++) {
+    const int b = r->s[i].own_lo;
+    if (b > drainrow - 3 && b < drainrow + 4) return 2;
+  }
+  r->p.drainrow = drainrow;
+  r->p.draincol = draincol;
+  r->drain_owner = 0;
+  for (int i = 0; i < r->n; i++)
+    if (drainrow >= r->s[i].own_lo && drainrow <= r->s[i].own_hi) r->drain_owner = i;
+  return wdpm_set_drain(r->c, drainrow, draincol);
+}
+
+static int rank_get_cell(wdpm_rank *r, int row, int col, double *water, double *dem) {
+  int owner = 0;
+  for (int i = 0; i < r->n; i++)
+    if (row >= r->s[i].own_lo && row <= r->s[i].own_hi) owner = i;
+  double mine[2] = {0.0, 0.0}, all[MAXR * 2];
+  if (r->rank == owner && wdpm_get_cell(r->c, row - (r->n > 1 ? r->s[owner].row0 : 0), col, &mine[0], &mine[1])) return 1;
+  if (rank_allgather(r, mine, 2, all)) return 1;
+  if (water) *water = all[2 * owner];
+  if (dem) *dem = all[2 * owner + 1];
+  return 0;
+}
+
+/* this rank's owned FILE rows into the whole un-padded raster at `water` */
+static int rank_download_unpadded(wdpm_rank *r, int mask, double *water) {
+  const wdpm_slab *me = &r->s[r->rank];
+  int f0 = (r->n > 1 ? me->own_lo : 0) - 1, f1 = (r->n > 1 ? me->own_hi : r->p.nrows + 1) - 1;   /* file rows of the owned padded rows */
+  if (f0 < 0) f0 = 0;
+  if (f1 > r->p.nrows - 1) f1 = r->p.nrows - 1;
+  if (f1 < f0) return 0;
+  return wdpm_download_unpadded(r->c, f0, f1 - f0 + 1, mask, water + (size_t)f0 * r->p.ncols);
+}
+
 /* ---- the ranks of one process, one host thread each ------------------------------------------- */
-enum { CMD_UPLOAD = 1, CMD_RUN_BLOCK, CMD_DRAIN_STATS, CMD_GET_TD, CMD_SET_TD, CMD_DOWNLOAD };
+enum { CMD_UPLOAD = 1, CMD_RUN_BLOCK, CMD_DRAIN_STATS, CMD_GET_TD, CMD_SET_TD, CMD_DOWNLOAD, CMD_UPLOAD_UNPADDED,
+       CMD_COUNT_STATS, CMD_FIND_DRAIN, CMD_SET_DRAIN, CMD_GET_CELL, CMD_DOWNLOAD_UNPADDED };
 
 static int group_execute(struct wdpm_group *g, int i) {
   wdpm_rank *r = g->r[i];
@@ -448,6 +542,21 @@ static int group_execute(struct wdpm_group *g, int i) {
     case CMD_SET_TD: return wdpm_rank_set_totaldrain(r, g->a_value);
     case CMD_DOWNLOAD:
       return wdpm_rank_download_owned(r, g->a_out + (g->n > 1 ? (size_t)r->s[i].own_lo * r->ncp : 0));
+    case CMD_UPLOAD_UNPADDED: return rank_upload_unpadded(r, g->a_dem, g->a_water, g->a_setup);
+    case CMD_COUNT_STATS: return rank_count_stats(r, &g->res_i[i], &g->res_j[i], &g->res_a[i]);
+    case CMD_FIND_DRAIN: {
+      int32_t dr = 0, dc = 0;
+      if (rank_find_drain(r, &g->res_a[i], &dr, &dc)) return 1;
+      g->res_i[i] = dr; g->res_j[i] = dc;
+      return 0;
+    }
+    case CMD_SET_DRAIN: {
+      const int rc = rank_set_drain(r, g->a_row, g->a_col);
+      g->res_i[i] = rc;
+      return rc == 2 ? 0 : rc;
+    }
+    case CMD_GET_CELL: return rank_get_cell(r, g->a_row, g->a_col, &g->res_a[i], &g->res_b[i]);
+    case CMD_DOWNLOAD_UNPADDED: return rank_download_unpadded(r, g->a_mask, g->a_out);
   }
   return rb_fail("wdpm_group: unknown command");
 }
@@ -618,4 +727,46 @@ int wdpm_group_enqueue_stats(wdpm_group *g, double *seconds, double *exchange_se
   if (exchange_seconds) *exchange_seconds = e;
   if (iterations) *iterations = g->r[0]->iters;
   return 0;
+}
+
+int wdpm_group_upload_unpadded(wdpm_group *g, const double *dem, const double *water, const wdpm_setup *setup) {
+  if (!dem || !setup) return rb_fail("wdpm_group_upload_unpadded: null argument");
+  g->a_dem = dem; g->a_water = water; g->a_setup = setup;
+  return group_dispatch(g, CMD_UPLOAD_UNPADDED);
+}
+
+int wdpm_group_count_stats(wdpm_group *g, int64_t *valid, int64_t *wet, double *maxv) {
+  if (group_dispatch(g, CMD_COUNT_STATS)) return 1;
+  if (valid) *valid = g->res_i[0];
+  if (wet) *wet = g->res_j[0];
+  if (maxv) *maxv = g->res_a[0];
+  return 0;
+}
+
+int wdpm_group_find_drain(wdpm_group *g, double *mindem, int32_t *drainrow, int32_t *draincol) {
+  if (group_dispatch(g, CMD_FIND_DRAIN)) return 1;
+  if (mindem) *mindem = g->res_a[0];
+  if (drainrow) *drainrow = (int32_t)g->res_i[0];
+  if (draincol) *draincol = (int32_t)g->res_j[0];
+  return 0;
+}
+
+int wdpm_group_set_drain(wdpm_group *g, int32_t drainrow, int32_t draincol) {
+  g->a_row = drainrow; g->a_col = draincol;
+  if (group_dispatch(g, CMD_SET_DRAIN)) return 1;
+  return (int)g->res_i[0];
+}
+
+int wdpm_group_get_cell(wdpm_group *g, int32_t row, int32_t col, double *water, double *dem) {
+  g->a_row = row; g->a_col = col;
+  if (group_dispatch(g, CMD_GET_CELL)) return 1;
+  if (water) *water = g->res_a[0];
+  if (dem) *dem = g->res_b[0];
+  return 0;
+}
+
+int wdpm_group_download_unpadded(wdpm_group *g, int32_t mask_missing, double *water) {
+  if (!water) return rb_fail("wdpm_group_download_unpadded: null array");
+  g->a_mask = mask_missing; g->a_out = water;
+  return group_dispatch(g, CMD_DOWNLOAD_UNPADDED);
 }

@@ -301,51 +301,12 @@ static void parse_command_line(int argc, char **argv, run_config *c) {
 typedef struct {
   int R, C;
   double missing, cellsize, cellarea;
-  double *dem, *water;          /* R x C */
-  double *bigdem, *bigwater;    /* (R+2) x (C+2) */
+  double *dem, *water;          /* R x C, as in the files */
+  int water_all_zero;           /* no water raster was read: the device starts from zeros, nothing is uploaded */
+  int apply_module_water;       /* the module's water adjustment is still to be applied (not on a resumed run) */
   double initial_vol, basin_area, totaldrain0;
   int basincount, drainrow, draincol;
 } raster_state;
-
-/* ---- elementwise host passes over big rasters run on several threads (WDPM_IO_THREADS, default =
- * online cores up to 16; rasters below 2^20 cells stay on one).  Only passes whose result does not
- * depend on the order of evaluation: the reference's volume sums stay sequential. ---------------- */
-typedef void (*range_fn)(size_t lo, size_t hi, int tid, void *ctx);
-typedef struct { range_fn fn; void *ctx; size_t lo, hi; int tid; } range_job;
-static void *range_main(void *arg) {
-  range_job *j = (range_job *)arg;
-  j->fn(j->lo, j->hi, j->tid, j->ctx);
-  return NULL;
-}
-#define MAX_HOST_THREADS 16
-static int host_threads(size_t n) {
-  const char *pm = getenv("WDPM_HOST_PAR_MIN");            /* cells below which a pass stays on one thread (tests lower it) */
-  if (n < (pm ? (size_t)atoll(pm) : (size_t)1 << 20)) return 1;
-  const char *e = getenv("WDPM_IO_THREADS");
-  long t = e ? atol(e) : sysconf(_SC_NPROCESSORS_ONLN);
-  if (t > MAX_HOST_THREADS) t = MAX_HOST_THREADS;
-  return t < 1 ? 1 : (int)t;
-}
-/* fn(lo, hi, tid, ctx) over [0, n) cut into one contiguous range per thread (n units of `weight`
- * cells each: cells or rows); returns the thread count */
-static int parallel_ranges_w(size_t n, size_t weight, range_fn fn, void *ctx) {
-  int T = host_threads(n * weight);
-  if ((size_t)T > n) T = n ? (int)n : 1;
-  if (T == 1) { fn(0, n, 0, ctx); return 1; }
-  pthread_t th[MAX_HOST_THREADS];
-  range_job job[MAX_HOST_THREADS];
-  int started = 0;
-  for (int t = 0; t < T; t++) {
-    job[t].fn = fn; job[t].ctx = ctx; job[t].tid = t;
-    job[t].lo = n / T * t; job[t].hi = t == T - 1 ? n : n / T * (t + 1);
-    if (pthread_create(&th[t], NULL, range_main, &job[t]) != 0) break;
-    started++;
-  }
-  for (int t = started; t < T; t++) range_main(&job[t]);          /* could not start it: do it here */
-  for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
-  return T;
-}
-static int parallel_ranges(size_t n, range_fn fn, void *ctx) { return parallel_ranges_w(n, 1, fn, ctx); }
 
 static double volume_where(const raster_state *s, double dem_above) {
   double v = 0;
@@ -353,20 +314,6 @@ static double volume_where(const raster_state *s, double dem_above) {
   for (size_t i = 0; i < n; i++)
     if (s->dem[i] > dem_above) v += s->water[i];
   return v * s->cellarea;
-}
-
-typedef struct { raster_state *s; const run_config *c; int flag; long count[MAX_HOST_THREADS]; double mx[MAX_HOST_THREADS]; } pass_ctx;
-
-static void zero_water_range(size_t lo, size_t hi, int tid, void *ctx) {
-  pass_ctx *p = (pass_ctx *)ctx;
-  raster_state *s = p->s;
-  (void)tid;
-  for (size_t i = lo; i < hi; i++)
-    if (!p->flag || s->dem[i] > s->missing) s->water[i] = 0;
-}
-static void zero_water(raster_state *s, int valid_only) {
-  pass_ctx p = {.s = s, .flag = valid_only};
-  parallel_ranges((size_t)s->R * s->C, zero_water_range, &p);
 }
 
 /* a raster file that exists but cannot be read: the reference dereferences the NULL FILE* and crashes;
@@ -390,54 +337,8 @@ static int load_or_create_water(const run_config *c, raster_state *s) {
   } else {
     printf("%30s\n", "Water file will be created");
   }
-  zero_water(s, c->module == WDPM_ADD);
+  s->water_all_zero = 1;       /* the calloc'ed raster: the device builds its zeros itself */
   return 0;
-}
-
-static void apply_module_water_range(size_t lo, size_t hi, int tid, void *ctx) {
-  pass_ctx *p = (pass_ctx *)ctx;
-  raster_state *s = p->s;
-  const run_config *c = p->c;
-  (void)tid;
-  if (c->module == WDPM_ADD) {
-    const double add = c->addwater / 1000.0, rof = c->rof;          /* WDPMCL.c:419 */
-    /* the reference makes two passes (:727-733 then :734-740); per cell they amount to: a wet cell gets
-     * += add and - now being > 0 or not - is looked at again by the second test, exactly as here */
-    for (size_t i = lo; i < hi; i++)
-      if (s->dem[i] > s->missing) {
-        if (s->water[i] > 0) s->water[i] += add;
-        if (s->water[i] <= 0) s->water[i] = add * rof;
-      }
-  } else if (c->module == WDPM_SUBTRACT) {
-    const double sub = c->subtractwater / 1000;                      /* :475 */
-    for (size_t i = lo; i < hi; i++)                                 /* :879-885 */
-      if (s->dem[i] > s->missing) {
-        const double d = s->water[i] - sub;
-        s->water[i] = d > 0 ? d : 0;
-      }
-  }
-}
-static void apply_module_water(const run_config *c, raster_state *s) {
-  pass_ctx p = {.s = s, .c = c};
-  parallel_ranges((size_t)s->R * s->C, apply_module_water_range, &p);
-}
-
-/* padded rows [lo, hi): border = (missing, 0), interior = the file rasters (WDPMCL.c:796-807) */
-static void pad_rows_range(size_t lo, size_t hi, int tid, void *ctx) {
-  raster_state *s = ((pass_ctx *)ctx)->s;
-  const size_t n = (size_t)s->C + 2;
-  (void)tid;
-  for (size_t i = lo; i < hi; i++) {
-    double *bd = s->bigdem + i * n, *bw = s->bigwater + i * n;
-    if (i == 0 || i == (size_t)s->R + 1) {
-      for (size_t j = 0; j < n; j++) { bd[j] = s->missing; bw[j] = 0; }
-      continue;
-    }
-    bd[0] = bd[n - 1] = s->missing;
-    bw[0] = bw[n - 1] = 0;
-    memcpy(bd + 1, s->dem + (i - 1) * s->C, (size_t)s->C * sizeof(double));
-    memcpy(bw + 1, s->water + (i - 1) * s->C, (size_t)s->C * sizeof(double));
-  }
 }
 
 static void announce_no_scratch(int module) {
@@ -484,7 +385,10 @@ static void prefer_lossless_scratch(const run_config *c, raster_state *s) {
   free(side);
 }
 
-static void setup_module(const run_config *c, raster_state *s) {
+/* the host half of the module set-up (WDPMCL.c:643-1034): which file the water raster comes from.  Applying
+ * the module's water adjustment, padding, the basin count, the drain-cell search and the volumes are done next
+ * to the rasters by the back-end (wdpm_group_upload_unpadded etc.). */
+static void prepare_water(const run_config *c, raster_state *s) {
   const int have_scratch_name = !is_null_name(c->scratch);
   int resumed = 0;
   /* :656-664 / :813-821 sum the water raster before anything has been read into it: every term is
@@ -511,77 +415,26 @@ static void setup_module(const run_config *c, raster_state *s) {
       read_grid_or_die(c->water, s->R, s->C, s->water);
     } else {
       const int read_file = load_or_create_water(c, s);
-      /* the reference recomputes the initial volume only on the scratch-name branch (:690-699, :846-855) */
+      /* the reference recomputes the initial volume only on the scratch-name branch (:690-699, :846-855), from the
+       * water file as read, with `dem > 0` for subtract: a sequential sum over the file raster, on the host */
       if (read_file && have_scratch_name)
         s->initial_vol = volume_where(s, c->module == WDPM_ADD ? s->missing : 0.0);
-      apply_module_water(c, s);
+      s->apply_module_water = 1;
     }
   }
-  /* padded arrays, WDPMCL.c:796-807 */
-  const int n = s->C + 2;
-  {
-    pass_ctx p = {.s = s};
-    parallel_ranges_w((size_t)s->R + 2, (size_t)n, pad_rows_range, &p);
-  }
-  if (c->module == WDPM_DRAIN) {
-    double mindrain = 100000000;                                               /* :1005-1017 */
-    for (int i = 0; i < s->R + 2; i++)
-      for (int j = 0; j < n; j++) {
-        const double d = s->bigdem[(size_t)i * n + j];
-        if (d > 0 && d < mindrain) { mindrain = d; s->drainrow = i; s->draincol = j; }
-      }
-    s->initial_vol = volume_where(s, s->missing);                              /* :1019-1028 */
-    const double wd = s->bigwater[(size_t)s->drainrow * n + s->draincol];
-    s->totaldrain0 = wd > 0 ? wd : 0;                                          /* :1029 */
-    s->basin_area = s->basincount * s->cellarea;
-    printf("%s\n", "               ");                                         /* :1820-1828 */
-    printf("%30s\n", "Basin summary");
-    printf("%20s %10.4f %s\n", "Basin area:", s->basin_area, "m2");
-    printf("%20s %10.4f %s\n", "Initial volume:", s->initial_vol, "m3");
-    printf("%20s %d\n", "Drain column:", s->draincol);
-    printf("%20s %d\n", "Drain row:", s->drainrow);
-    printf("%20s %10.4f %s\n", "Min DEM elevation:", s->bigdem[(size_t)s->drainrow * n + s->draincol], "m");
-  }
-  iteration_headings(c->module);
 }
 
-static void unpad_rows_range(size_t lo, size_t hi, int tid, void *ctx) {
-  pass_ctx *p = (pass_ctx *)ctx;
-  raster_state *s = p->s;
-  const size_t n = (size_t)s->C + 2;
-  (void)tid;
-  for (size_t i = lo; i < hi; i++)
-    for (size_t j = 0; j < (size_t)s->C; j++) {
-      const size_t k = i * s->C + j;
-      s->water[k] = s->bigwater[(i + 1) * n + j + 1];
-      if (p->flag && s->dem[k] <= s->missing) s->water[k] = s->missing;
+/* the drain cell on the host (WDPMCL.c:1005-1017 on the padded raster, whose border holds the NODATA value):
+ * only for rasters whose NODATA value is not negative - there a NODATA cell can itself be the smallest
+ * elevation > 0, which the device copy of the DEM (NODATA = +inf) cannot say */
+static void find_drain_on_host(raster_state *s) {
+  double mindrain = 100000000;
+  for (int i = 0; i < s->R + 2; i++)
+    for (int j = 0; j < s->C + 2; j++) {
+      const int border = i == 0 || j == 0 || i == s->R + 1 || j == s->C + 1;
+      const double d = border ? s->missing : s->dem[(size_t)(i - 1) * s->C + (j - 1)];
+      if (d > 0 && d < mindrain) { mindrain = d; s->drainrow = i; s->draincol = j; }
     }
-}
-static void unpad_water(raster_state *s, int mask_missing) {
-  pass_ctx p = {.s = s, .flag = mask_missing};
-  parallel_ranges_w((size_t)s->R, (size_t)s->C, unpad_rows_range, &p);
-}
-
-/* counts and the maximum of the final statistics (WDPMCL.c:1394-1459): order-free, so threaded; the
- * reference seeds the maximum with water[0][0] and lets `>` decide, so a NaN cell never wins unless it
- * is that seed - kept by seeding every range with -inf and folding the ranges into water[0] in order */
-static void count_valid_range(size_t lo, size_t hi, int tid, void *ctx) {
-  pass_ctx *p = (pass_ctx *)ctx;
-  long c = 0;
-  for (size_t i = lo; i < hi; i++) c += p->s->dem[i] > p->s->missing;
-  p->count[tid] = c;
-}
-static void final_counts_range(size_t lo, size_t hi, int tid, void *ctx) {
-  pass_ctx *p = (pass_ctx *)ctx;
-  const raster_state *s = p->s;
-  long c = 0;
-  double mx = -INFINITY;
-  for (size_t i = lo; i < hi; i++) {
-    c += s->water[i] > 0.001 && s->dem[i] > s->missing;
-    if (s->water[i] > mx) mx = s->water[i];
-  }
-  p->count[tid] = c;
-  p->mx[tid] = mx;
 }
 
 /* devices to spread the raster over: WDPM_DEVICES=a,b,c | WDPM_GPUS=N (0..N-1) | WDPM_DEVICE=n | 0 */
@@ -739,26 +592,22 @@ int main(int argc, char **argv) {
     return 1;
   }
   printf("%30s\n", "Setting array sizes");
-  const size_t ncell = (size_t)st.R * st.C, nbig = (size_t)(st.R + 2) * (st.C + 2);
-  st.dem = (double *)calloc(ncell, sizeof(double));
-  st.water = (double *)calloc(ncell, sizeof(double));
-  /* the two rasters that travel to and from the device come from the library (page-locked on the
-   * HIP back-end) when the run writes checkpoints, i.e. downloads the raster after every block:
-   * page-locking costs ~0.3 s per GiB once and saves ~40 ms per GiB on every transfer (measured at
-   * 8192^2), so a run with three transfers in all is better off with ordinary memory.
-   * WDPM_PINNED=0/1 overrides. */
+  const size_t ncell = (size_t)st.R * st.C;
+  /* the host holds the two FILE rasters only; the padded rasters, the snapshot and the ping-pong partner live
+   * on the device.  The water raster comes from the library (page-locked on the HIP back-end) when the run
+   * writes checkpoints, i.e. downloads it after every block: page-locking costs ~0.3 s per GiB once and saves
+   * ~40 ms per GiB on every transfer (measured at 8192^2).  WDPM_PINNED=0/1 overrides. */
   const int pinned = getenv("WDPM_PINNED") ? atoi(getenv("WDPM_PINNED")) != 0 : !is_null_name(cfg.scratch);
+  st.dem = (double *)malloc(ncell * sizeof(double));
   if (pinned) {
-    void *a = NULL, *b = NULL;
-    ABI_TRY(wdpm_host_alloc(nbig * sizeof(double), &a));
-    ABI_TRY(wdpm_host_alloc(nbig * sizeof(double), &b));
-    st.bigdem = (double *)a;
-    st.bigwater = (double *)b;
+    void *a = NULL;
+    ABI_TRY(wdpm_host_alloc(ncell * sizeof(double), &a));
+    st.water = (double *)a;
+    if (st.water) memset(st.water, 0, ncell * sizeof(double));
   } else {
-    st.bigdem = (double *)malloc(nbig * sizeof(double));
-    st.bigwater = (double *)malloc(nbig * sizeof(double));
+    st.water = (double *)calloc(ncell, sizeof(double));
   }
-  if (!st.dem || !st.water || !st.bigdem || !st.bigwater) {
+  if (!st.dem || !st.water) {
     fprintf(stderr, "WDPMCL: out of memory\n");
     return 1;
   }
@@ -767,14 +616,9 @@ int main(int argc, char **argv) {
   phase("read DEM");
   printf("%s\n", "           ");
   printf("%s\n", "           ");
-  {
-    pass_ctx p = {.s = &st};
-    const int T = parallel_ranges(ncell, count_valid_range, &p);               /* :643-650 */
-    for (int t = 0; t < T; t++) st.basincount += (int)p.count[t];
-  }
 
-  setup_module(&cfg, &st);
-  phase("set-up (water file, module)");
+  prepare_water(&cfg, &st);
+  phase("set-up (water file)");
 
   /* unit conversions, WDPMCL.c:417-420 / :473-476 / :528-530 */
   const double eltol = cfg.eltol / 1000.0;
@@ -786,24 +630,75 @@ int main(int argc, char **argv) {
   p.module = cfg.module;
   p.nrows = st.R;
   p.ncols = st.C;
-  p.drainrow = st.drainrow;
-  p.draincol = st.draincol;
   p.missingvalue = st.missing;
+  /* drain: the outlet is found on the device once the DEM is there; a NODATA value >= 0 needs the host's search */
+  const int host_drain_search = cfg.module == WDPM_DRAIN && !(st.missing < 0);
+  if (host_drain_search) find_drain_on_host(&st);
+  p.drainrow = cfg.module == WDPM_DRAIN ? (host_drain_search ? st.drainrow : -1) : 0;
+  p.draincol = cfg.module == WDPM_DRAIN ? (host_drain_search ? st.draincol : -1) : 0;
   int32_t devices[64];
-  int ndev = device_list(devices, 64);
+  const int ndev_asked = device_list(devices, 64);
+  const int every = getenv("WDPM_EXCHANGE_EVERY") ? atoi(getenv("WDPM_EXCHANGE_EVERY")) : 4;
+  wdpm_setup su;
+  memset(&su, 0, sizeof su);
+  if (st.apply_module_water) {
+    su.op = cfg.module == WDPM_ADD ? 1 : 2;
+    su.add = cfg.addwater / 1000.0;                                            /* WDPMCL.c:419 */
+    su.rof = cfg.rof;
+    su.sub = cfg.subtractwater / 1000;                                         /* :475 */
+  }
   wdpm_group *ctx = NULL;
-  ABI_TRY(wdpm_group_create(&ctx, &p, ndev, devices, getenv("WDPM_EXCHANGE_EVERY") ? atoi(getenv("WDPM_EXCHANGE_EVERY")) : 4));
-  ndev = wdpm_group_size(ctx);
+  int ndev = 0;
+  for (int attempt = 0; attempt < 2; attempt++) {
+    ABI_TRY(wdpm_group_create(&ctx, &p, ndev_asked, devices, every));
+    ndev = wdpm_group_size(ctx);
+    /* padded rasters built on the device from the file rasters, module water applied on the way (:727-740, :796-807, :879-885) */
+    ABI_TRY(wdpm_group_upload_unpadded(ctx, st.dem, st.water_all_zero ? NULL : st.water, &su));
+    if (cfg.module != WDPM_DRAIN || host_drain_search || attempt == 1) break;
+    double mindem = 0;
+    int32_t dr = 0, dc = 0;
+    ABI_TRY(wdpm_group_find_drain(ctx, &mindem, &dr, &dc));                    /* :1005-1017 */
+    st.drainrow = dr;
+    st.draincol = dc;
+    const int rc = wdpm_group_set_drain(ctx, dr, dc);
+    if (rc == 0) break;
+    if (rc != 2) { fprintf(stderr, "WDPMCL: wdpm_group_set_drain: %s\n", wdpm_last_error()); return 1; }
+    /* the outlet sits next to a slab boundary of the partition made without knowing it: partition again */
+    wdpm_group_destroy(ctx);
+    ctx = NULL;
+    p.drainrow = dr;
+    p.draincol = dc;
+  }
   {
     static const char *const halo_name[] = {"", ", halos by RCCL send/recv", ", halos by peer copies", ", halos through the host"};
     const int hk = wdpm_group_halo(ctx);
-    fprintf(stderr, "WDPMCL: redistribution loop on back-end %s, %d device%s (first: %d)%s\n", wdpm_backend_name(), ndev,
-            ndev == 1 ? "" : "s, row-block decomposition, one host thread per device", devices[0],
+    fprintf(stderr, "WDPMCL: redistribution loop, set-up and statistics on back-end %s, %d device%s (first: %d)%s\n",
+            wdpm_backend_name(), ndev, ndev == 1 ? "" : "s, row-block decomposition, one host thread per device", devices[0],
             ndev > 1 && hk >= 0 && hk < 4 ? halo_name[hk] : "");
   }
-  ABI_TRY(wdpm_group_upload(ctx, st.bigdem, st.bigwater));
-  if (cfg.module == WDPM_DRAIN) ABI_TRY(wdpm_group_set_totaldrain(ctx, st.totaldrain0));
-  phase("create contexts + upload");
+  {
+    int64_t valid = 0;
+    ABI_TRY(wdpm_group_count_stats(ctx, &valid, NULL, NULL));                  /* basincount, :643-650 */
+    st.basincount = (int)valid;
+  }
+  if (cfg.module == WDPM_DRAIN) {
+    double sum = 0, wd = 0, dmin = 0;
+    ABI_TRY(wdpm_group_drain_stats(ctx, NULL, &sum));                          /* :1019-1028, the sequential sum */
+    st.initial_vol = sum * st.cellarea;
+    ABI_TRY(wdpm_group_get_cell(ctx, st.drainrow, st.draincol, &wd, &dmin));
+    st.totaldrain0 = wd > 0 ? wd : 0;                                          /* :1029 */
+    ABI_TRY(wdpm_group_set_totaldrain(ctx, st.totaldrain0));
+    st.basin_area = st.basincount * st.cellarea;
+    printf("%s\n", "               ");                                         /* :1820-1828 */
+    printf("%30s\n", "Basin summary");
+    printf("%20s %10.4f %s\n", "Basin area:", st.basin_area, "m2");
+    printf("%20s %10.4f %s\n", "Initial volume:", st.initial_vol, "m3");
+    printf("%20s %d\n", "Drain column:", st.draincol);
+    printf("%20s %d\n", "Drain row:", st.drainrow);
+    printf("%20s %10.4f %s\n", "Min DEM elevation:", dmin, "m");
+  }
+  iteration_headings(cfg.module);
+  phase("contexts, upload, set-up on the device");
 
   /* block loop, WDPMCL.c:1049-1377 */
   struct timeval t0;
@@ -830,8 +725,8 @@ int main(int argc, char **argv) {
     if (cfg.module == WDPM_DRAIN && diffdrain < draintol) done = 1;            /* :1287,1303 */
     if (cfg.iteration_limit > 0 && k >= cfg.iteration_limit) done = 1;
     if (!done && write_scratch) {                                              /* checkpoint, :1290-1372 */
-      ABI_TRY(wdpm_group_download_water(ctx, st.bigwater));
-      unpad_water(&st, cfg.module == WDPM_ADD);
+      /* un-padded (and, for add, NODATA-masked :1336-1344) on the device, straight into the file raster */
+      ABI_TRY(wdpm_group_download_unpadded(ctx, cfg.module == WDPM_ADD, st.water));
       scratch_submit(&scratch, st.water);
     }
   }
@@ -839,24 +734,20 @@ int main(int argc, char **argv) {
   if (write_scratch) scratch_finish(&scratch);
   phase("wait for checkpoint writer");
 
-  double totaldrain = 0, device_sum = 0;
-  /* watertotal of the final statistics (:1405-1412) is the same sequential row-major sum over the valid
-   * cells as the drain module's final_vol: the back-end evaluates it (the HIP one on the device, exactly) */
-  ABI_TRY(wdpm_group_drain_stats(ctx, NULL, &device_sum));
-  ABI_TRY(wdpm_group_download_water(ctx, st.bigwater));
+  /* final statistics, WDPMCL.c:1379-1467, next to the raster: the sequential volume sum (:1405-1412, exact),
+   * the wet-cell count (:1397-1404) and the maximum (:1448-1457); the raster comes down un-padded and masked
+   * (:1379-1392) for the output file only */
+  double totaldrain = 0, watertotal = 0, dev_max = 0;
+  int64_t wet = 0;
+  ABI_TRY(wdpm_group_drain_stats(ctx, NULL, &watertotal));
+  ABI_TRY(wdpm_group_count_stats(ctx, NULL, &wet, &dev_max));
+  ABI_TRY(wdpm_group_download_unpadded(ctx, 1, st.water));
   if (cfg.module == WDPM_DRAIN) ABI_TRY(wdpm_group_get_totaldrain(ctx, &totaldrain));
   wdpm_group_destroy(ctx);
-  phase("download + destroy");
+  phase("statistics + download + destroy");
 
-  /* final statistics, WDPMCL.c:1379-1467 */
-  unpad_water(&st, 1);
-  int watercount = 0;
-  double watertotal = 0, final_vol = 0;
-  pass_ctx fin = {.s = &st};
-  const int finT = parallel_ranges(ncell, final_counts_range, &fin);
-  for (int t = 0; t < finT; t++) watercount += (int)fin.count[t];
-  watertotal = device_sum;
-  final_vol = watertotal * st.cellarea;
+  const int watercount = (int)wet;
+  const double final_vol = watertotal * st.cellarea;
   const double meanwater = watertotal / ((float)watercount);
   const double waterfrac = (float)watercount / (float)st.basincount;
   double drainvol = 0, draindepth = 0;
@@ -864,12 +755,12 @@ int main(int argc, char **argv) {
     drainvol = totaldrain * st.cellarea;
     draindepth = (drainvol / ((float)st.basincount * st.cellarea)) * 1000;
   }
+  /* the reference seeds the maximum with water[0][0] of the masked raster and lets `>` decide, so a NaN cell
+   * never wins unless it is that seed: the device's maximum (from -inf) is folded into the seed the same way */
   double maxdepth = st.water[0];
-  for (int t = 0; t < finT; t++)
-    if (fin.mx[t] > maxdepth) maxdepth = fin.mx[t];
+  if (dev_max > maxdepth) maxdepth = dev_max;
   maxdepth = maxdepth * 1000;
 
-  phase("final statistics");
   printf("%s\n", "                     ");                                      /* :1832-1857 */
   printf("%30s\n", "WDPM run summary");
   printf("%20s %10.2f %s\n", "Initial volume", st.initial_vol, "m3");
@@ -888,7 +779,7 @@ int main(int argc, char **argv) {
   asc_write_grid(cfg.output, &hdr, st.R, st.C, st.water);
   phase("write output raster");
   printf("%20s %10.2f %s\n", "Run Time", seconds_since(&t0), "s");
-  free(st.dem); free(st.water);
-  if (pinned) { wdpm_host_free(st.bigdem); wdpm_host_free(st.bigwater); } else { free(st.bigdem); free(st.bigwater); }
+  free(st.dem);
+  if (pinned) wdpm_host_free(st.water); else free(st.water);
   return 0;
 }

@@ -314,6 +314,44 @@ class Group:
         self.lib.check(self.lib.dll.wdpm_group_drain_stats(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    # -- set-up and final statistics next to the rasters
+    def upload_unpadded(self, dem, water=None, op: int = 0, add: float = 0.0, rof: float = 0.0, sub: float = 0.0):
+        from .capi import SetupStruct
+        shape = (self.shape[0] - 2, self.shape[1] - 2)
+        d = Context._arr(dem, shape)
+        w = None if water is None else Context._arr(water, shape)
+        su = SetupStruct(op, add, rof, sub)
+        self.lib.check(self.lib.dll.wdpm_group_upload_unpadded(self._h, d.ctypes.data, None if w is None else w.ctypes.data,
+                                                               C.byref(su)))
+
+    def count_stats(self):
+        """(valid cells, valid cells with water > 0.001, max over cells of (valid ? water : missing))"""
+        a, b, m = C.c_int64(), C.c_int64(), C.c_double()
+        self.lib.check(self.lib.dll.wdpm_group_count_stats(self._h, C.byref(a), C.byref(b), C.byref(m)))
+        return a.value, b.value, m.value
+
+    def find_drain(self):
+        m, r, c = C.c_double(), C.c_int32(), C.c_int32()
+        self.lib.check(self.lib.dll.wdpm_group_find_drain(self._h, C.byref(m), C.byref(r), C.byref(c)))
+        return m.value, r.value, c.value
+
+    def set_drain(self, drainrow: int, draincol: int) -> int:
+        """0 = set; 2 = the outlet is too close to a slab boundary of this partition (create the group again)"""
+        rc = self.lib.dll.wdpm_group_set_drain(self._h, drainrow, draincol)
+        if rc not in (0, 2):
+            self.lib.check(rc)
+        return rc
+
+    def get_cell(self, row: int, col: int):
+        w, d = C.c_double(), C.c_double()
+        self.lib.check(self.lib.dll.wdpm_group_get_cell(self._h, row, col, C.byref(w), C.byref(d)))
+        return w.value, d.value
+
+    def download_unpadded(self, mask_missing: bool = True) -> np.ndarray:
+        out = np.empty((self.shape[0] - 2, self.shape[1] - 2))
+        self.lib.check(self.lib.dll.wdpm_group_download_unpadded(self._h, int(mask_missing), out.ctypes.data))
+        return out
+
     def enqueue_stats(self):
         """(seconds queueing launches, seconds in halo refreshes) summed over ranks, iterations of one rank"""
         s, e, n = C.c_double(), C.c_double(), C.c_int64()
