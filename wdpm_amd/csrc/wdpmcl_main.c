@@ -15,6 +15,10 @@
  *   - runoff.cl is not needed in the working directory.
  *   - malformed invocations that make the reference read uninitialised memory (unknown module with
  *     12/13 arguments, short parameter file) print the usage text and exit 42 instead.
+ *   - WDPM_REPORT_BACKEND=1 adds one line to the report (after the "Using ... for Computation" lines) naming the
+ *     back-end, the devices and the decomposition actually used; off by default so that stdout stays the reference's.
+ *   - WDPM_COLOR_RELIEF=<colour map file> hands the output raster to `gdaldem color-relief` once it is written,
+ *     as the reference's src/cmap_black.sh does for the GUI's PNG button (<output>.png; the .aux.xml is removed).
  *   - WDPM_DEVICE=<n> selects the HIP device (default 0).  WDPM_GPUS=<N> spreads the raster over
  *     devices 0..N-1 by row blocks (WDPM_DEVICES=a,b,c names them explicitly), one host thread per device,
  *     exchanging halo rows every WDPM_EXCHANGE_EVERY iterations (default 4) by RCCL send/recv
@@ -28,6 +32,7 @@
 #include <string.h>
 #include <sys/stat.h>
 #include <sys/time.h>
+#include <sys/wait.h>
 #include <unistd.h>
 
 #include "../../include/wdpm.h"
@@ -551,6 +556,55 @@ static void phase(const char *name) {
   gettimeofday(&last, NULL);
 }
 
+/* ---- gdaldem hand-off (reference: src/cmap_black.sh:1-10, run by the GUI's PNG button, src/WDPM.py:657-671) ----
+ * The helper process is forked at program start, before anything has touched the GPU (a process that has
+ * initialised the GPU must not exec another program), and sleeps on a pipe until the output raster is on disk. */
+typedef struct { pid_t pid; int fd; char png[600]; } relief_helper;
+
+static void relief_start(relief_helper *h, const char *output) {
+  h->pid = -1;
+  h->fd = -1;
+  const char *map = getenv("WDPM_COLOR_RELIEF");
+  if (!map || !*map) return;
+  snprintf(h->png, sizeof h->png, "%s", output);
+  char *dot = strrchr(h->png, '.');
+  if (dot && !strchr(dot, '/')) *dot = 0;                          /* outfile="${infile%.*}" */
+  strncat(h->png, ".png", sizeof h->png - strlen(h->png) - 1);
+  int pfd[2];
+  if (pipe(pfd) != 0) return;
+  const pid_t pid = fork();
+  if (pid < 0) { close(pfd[0]); close(pfd[1]); return; }
+  if (pid == 0) {
+    close(pfd[1]);
+    char go = 0;
+    if (read(pfd[0], &go, 1) != 1 || go != 'g') _exit(0);          /* the run ended without an output raster */
+    execlp("gdaldem", "gdaldem", "color-relief", output, map, "-OF", "png", h->png, (char *)NULL);
+    _exit(127);
+  }
+  close(pfd[0]);
+  h->pid = pid;
+  h->fd = pfd[1];
+}
+
+static void relief_finish(relief_helper *h) {
+  if (h->pid < 0) return;
+  const char go = 'g';
+  int status = 0;
+  if (write(h->fd, &go, 1) != 1) status = -1;
+  close(h->fd);
+  if (waitpid(h->pid, &status, 0) < 0) status = -1;
+  if (WIFEXITED(status) && WEXITSTATUS(status) == 0) {
+    char aux[640];
+    snprintf(aux, sizeof aux, "%s.aux.xml", h->png);
+    unlink(aux);                                                   /* "delete superfluous xml file" */
+    fprintf(stderr, "WDPMCL: colour relief written to %s\n", h->png);
+  } else if (WIFEXITED(status) && WEXITSTATUS(status) == 127) {
+    fprintf(stderr, "WDPMCL: WDPM_COLOR_RELIEF is set but gdaldem could not be started\n");
+  } else {
+    fprintf(stderr, "WDPMCL: gdaldem color-relief failed\n");
+  }
+}
+
 #define ABI_TRY(call)                                                      \
   do {                                                                     \
     if ((call) != 0) {                                                     \
@@ -563,6 +617,8 @@ int main(int argc, char **argv) {
   setbuf(stdout, NULL);
   run_config cfg;
   parse_command_line(argc, argv, &cfg);
+  relief_helper relief;
+  relief_start(&relief, cfg.output);       /* before anything touches the GPU */
   echo_parameters(&cfg);
 
   phase(NULL);
@@ -675,6 +731,9 @@ int main(int argc, char **argv) {
     fprintf(stderr, "WDPMCL: redistribution loop, set-up and statistics on back-end %s, %d device%s (first: %d)%s\n",
             wdpm_backend_name(), ndev, ndev == 1 ? "" : "s, row-block decomposition, one host thread per device", devices[0],
             ndev > 1 && hk >= 0 && hk < 4 ? halo_name[hk] : "");
+    if (getenv("WDPM_REPORT_BACKEND") && atoi(getenv("WDPM_REPORT_BACKEND")) != 0)   /* opt-in: the report is no longer the reference's */
+      printf("%41s %s, %d device%s%s\n", "Computation back-end:", wdpm_backend_name(), ndev, ndev == 1 ? "" : "s (row blocks)",
+             ndev > 1 && hk >= 0 && hk < 4 ? halo_name[hk] : "");
   }
   {
     int64_t valid = 0;
@@ -778,6 +837,7 @@ int main(int argc, char **argv) {
 
   asc_write_grid(cfg.output, &hdr, st.R, st.C, st.water);
   phase("write output raster");
+  relief_finish(&relief);
   printf("%20s %10.2f %s\n", "Run Time", seconds_since(&t0), "s");
   free(st.dem);
   if (pinned) wdpm_host_free(st.water); else free(st.water);
