@@ -300,8 +300,16 @@ int  wdpm_group_enqueue_stats(wdpm_group *grp, double *seconds, double *exchange
  *   from decimal text are); results are identical either way.  Setting 0 forces the fp64 DEM,
  *   setting 1 is honoured only for a DEM that passed the check; the kernel then uses the codes on
  *   launches large enough for them to pay (>= 4096^2 or so), setting 2 on launches of any size.  WDPM_DEM32=0 in the environment
- *   disables the encoding altogether, WDPM_DEM32=2 makes 2 the default.  The CPU restatement reports 0. */
-enum { WDPM_OPT_SIGNED_ZERO_SAFE = 1, WDPM_OPT_DEM32 = 2 };
+ *   disables the encoding altogether, WDPM_DEM32=2 makes 2 the default.  The CPU restatement reports 0.
+ * WDPM_OPT_TILES (get/set): 1 (default; WDPM_TILES=0 in the environment: 0) = dry-tile skipping.  The reference
+ *   skips dry centres cell by cell (WDPMCL.c:1099); the iteration kernel keeps, per water raster, one flag per
+ *   tile (the output block of one wave) saying "all +0.0", and a wave whose tile and eight neighbours are flagged
+ *   neither loads nor - when the output raster's block is known to hold zeros too - stores anything.  Results
+ *   are identical either way.  WDPM_OPT_TILES_SEEN / _WORKED (get): tiles of flag-keeping launches and those
+ *   among them that did work, summed at every wdpm_max_diff.  WDPM_OPT_SPARSE (get/set): the kernel marches
+ *   short chunks because most tiles were dry in the last block (the library switches by itself). */
+enum { WDPM_OPT_SIGNED_ZERO_SAFE = 1, WDPM_OPT_DEM32 = 2, WDPM_OPT_TILES = 3, WDPM_OPT_TILES_SEEN = 4,
+       WDPM_OPT_TILES_WORKED = 5, WDPM_OPT_SPARSE = 6 };
 int wdpm_get_option(wdpm_ctx *ctx, int32_t key, int64_t *value);
 int wdpm_set_option(wdpm_ctx *ctx, int32_t key, int64_t value);
 

@@ -1,0 +1,97 @@
+"""Dry-tile skipping (wdpm_kernels.h::TileFlags): rasters that are mostly dry land with water that spreads from a
+few places, against the oracle.  The flags must never change a bit of the result - and must actually skip work."""
+import numpy as np
+import pytest
+
+import wdpm_amd
+from helpers import bits_equal, find_drain, n_bit_diff, pad
+
+pytestmark = pytest.mark.gpu
+MISS = -99999.0
+
+
+def dry_case(R, C, seed, nodata=True):
+    """a tilted, bumpy DEM; water only in a few blobs high up, so that it runs down across tile boundaries"""
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:R, 0:C]
+    dem = np.round(520.0 - 0.02 * x - 0.03 * y + 0.3 * np.sin(x / 7.0) * np.cos(y / 5.0) + 0.05 * rng.random((R, C)), 4)
+    if nodata:
+        dem[rng.random((R, C)) < 0.03] = MISS
+        dem[R // 2:R // 2 + 20, C // 3:C // 3 + 60] = MISS
+    water = np.zeros((R, C))
+    for (r, c) in [(10, 20), (R // 3, C // 2), (R // 2 + 30, C - 40)]:
+        water[r:r + 9, c:c + 13] = 0.4 * rng.random((9, 13)) + 0.05
+    water[dem <= MISS] = 0.0
+    return dem, water
+
+
+def run_pair(hip, oracle, module, R, C, script, chunk, seed=1, tiles=1, sparse=None, **kw):
+    dem, water = dry_case(R, C, seed)
+    bd, bw = pad(dem, water, MISS)
+    ckw = dict(module=module, nrows=R, ncols=C, missingvalue=MISS, **kw)
+    if module == "drain":
+        dr, dc = find_drain(bd)
+        ckw.update(drainrow=dr, draincol=dc)
+    with hip.context(kernel=wdpm_amd.KERNEL_FUSED, chunk_rows=chunk, **ckw) as g, oracle.context(**ckw) as o:
+        g.set_option(wdpm_amd.capi.OPT_TILES, tiles)
+        if sparse is not None:
+            g.set_option(wdpm_amd.capi.OPT_SPARSE, sparse)
+        for c in (g, o):
+            c.upload(bd, bw)
+            c.totaldrain = 0.0
+        for op in script:
+            for c in (g, o):
+                if op[0] == "it":
+                    c.iterate(op[1])
+                elif op[0] == "begin":
+                    c.begin_block(op[1])
+                elif op[0] == "rows":
+                    c.upload_rows(op[1], op[2])
+            if op[0] == "check":
+                assert n_bit_diff(g.download_water(), o.download_water()) == 0, op
+                assert g.max_diff() == o.max_diff()
+                if module == "drain":
+                    assert g.totaldrain == o.totaldrain
+        seen, worked = g.get_option(wdpm_amd.capi.OPT_TILES_SEEN), g.get_option(wdpm_amd.capi.OPT_TILES_WORKED)
+        return seen, worked, g.get_option(wdpm_amd.capi.OPT_SPARSE)
+
+
+@pytest.mark.parametrize("module", ["add", "drain"])
+@pytest.mark.parametrize("chunk", [6, 12, 30])
+def test_dry_tiles_are_skipped_and_nothing_changes(hip, oracle, module, chunk):
+    R, C = 210, 700
+    rows = np.zeros((3, C + 2))
+    rows[:, 300:340] = 0.2                                   # water arriving from outside into a dry region
+    script = [("begin", 1e-4), ("it", 7), ("check",), ("it", 20), ("check",), ("begin", 2e-3), ("it", 15), ("check",),
+              ("rows", 150, rows), ("it", 9), ("check",), ("it", 30), ("check",)]
+    seen, worked, _ = run_pair(hip, oracle, module, R, C, script, chunk)
+    assert seen > 0 and worked < 0.8 * seen, (seen, worked)     # a good part of the tiles never did any work
+    seen0, worked0, _ = run_pair(hip, oracle, module, R, C, script, chunk, tiles=0)
+    assert seen0 == 0 and worked0 == 0                          # switched off: the flags are not even kept
+
+
+def test_sparse_mode_marches_short_chunks(hip, oracle):
+    """a raster tall enough for the short-chunk mode: forced on, the library's own switch observed, same bits"""
+    R, C = 800, 380
+    script = [("begin", 1e-4), ("it", 12), ("check",), ("begin", 1e-4), ("it", 12), ("check",)]
+    seen, worked, sparse = run_pair(hip, oracle, "add", R, C, script, 0, sparse=1)
+    assert sparse == 1 and seen > 0 and worked < 0.7 * seen
+    # left to itself the library goes sparse after the first block (most tiles dry) - WDPM_TRI=0-sized rasters only
+    seen, worked, sparse = run_pair(hip, oracle, "add", R, C, script, 0)
+    assert seen == 0 or sparse in (0, 1)
+
+
+@pytest.mark.parametrize("k", [1, 3])
+def test_dry_tiles_across_slabs(hip, oracle, k):
+    """several slabs of one GPU with peer-copied halos: rows arriving from a neighbour make tiles wet again"""
+    from wdpm_amd.rowblock import Group
+    R, C = 420, 520
+    dem, water = dry_case(R, C, 4)
+    bd, bw = pad(dem, water, MISS)
+    res = {}
+    for name, lib, devices in (("hip", hip, [0, 0, 0]), ("oracle", oracle, [0])):
+        with Group(lib, "add", R, C, MISS, devices, exchange_every=k, chunk_rows=12 if lib is hip else 0) as g:
+            g.upload(bd, bw)
+            mds = [g.run_block(17, 1e-4), g.run_block(23, 1e-4)]
+            res[name] = (g.download_water(), mds)
+    assert bits_equal(res["hip"][0], res["oracle"][0]) and res["hip"][1] == res["oracle"][1]

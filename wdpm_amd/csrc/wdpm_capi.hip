@@ -20,6 +20,8 @@
 
 #include "wdpm_ctx.h"
 
+constexpr int kSparseChunkRows = 96;   /* chunk height of the iteration kernel once most tiles are dry */
+
 static thread_local char g_err[512] = "";
 
 int wdpm_fail(const char *fmt, ...) {
@@ -36,6 +38,10 @@ int wdpm_fail(const char *fmt, ...) {
     hipError_t e_ = (expr);                                                                   \
     if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
   } while (0)
+
+struct wdpm_ctx;
+static int tiles_touch(wdpm_ctx *x, int slot, int row, int nrows);
+int wdpm_tiles_touch(wdpm_ctx *x, int row, int nrows) { return tiles_touch(x, x->cur, row, nrows); }
 
 extern "C" {
 
@@ -59,6 +65,21 @@ static int bind(wdpm_ctx *x) {
  * wdpm_max_diff reads it (applying the same flush on the fly).  At 16384^2 that is 1.3 ms per block
  * that no longer exists.  Whoever needs the current raster flushed in memory, or wants to write
  * into it, asks for that first: */
+/* rows [row, row + nrows) of d_w[slot] are about to be (or have been) written by somebody other than the
+ * iteration kernel: the tiles they touch are no longer known to be dry */
+static int tiles_touch(wdpm_ctx *x, int slot, int row, int nrows) {
+  if (!x->zero_valid[slot] || nrows <= 0) return 0;
+  if (x->tile_H < 6 || x->tile_nchunks < 1) { x->zero_valid[slot] = false; return 0; }
+  /* chunk i's block is rows [H*i + 2 (0 for i = 0), H*(i+1) + 1] */
+  int c0 = (row - 2) / x->tile_H, c1 = (row + nrows - 1 - 2) / x->tile_H;
+  if (row < 2) c0 = 0;
+  if (c0 < 0) c0 = 0;
+  if (c1 > x->tile_nchunks - 1) c1 = x->tile_nchunks - 1;
+  if (c1 < c0) return 0;
+  HIP_TRY(hipMemsetAsync(x->d_zero[slot] + (size_t)c0 * x->tile_nstrips, 0, (size_t)(c1 - c0 + 1) * x->tile_nstrips, x->stream));
+  return 0;
+}
+
 static int free_slot(const wdpm_ctx *x) {            /* a raster that is neither current nor the snapshot */
   for (int i = 0; i < 3; i++)
     if (i != x->cur && i != x->old) return i;
@@ -95,6 +116,7 @@ static int ensure_private(wdpm_ctx *x) {
   } else {
     HIP_TRY(hipMemcpyAsync(x->d_w[t], x->d_w[x->cur], x->cells * sizeof(double), hipMemcpyDeviceToDevice, x->stream));
   }
+  x->zero_valid[t] = false;      /* a copy: its flags could be copied too, but whoever asked is about to write into it */
   x->cur = t;
   return 0;
 }
@@ -103,6 +125,7 @@ static int ensure_private(wdpm_ctx *x) {
 static int ensure_fresh_slot(wdpm_ctx *x) {
   if (ensure_flushed(x)) return 1;
   if (x->cur == x->old) x->cur = free_slot(x);
+  x->zero_valid[x->cur] = false;
   return 0;
 }
 
@@ -153,6 +176,11 @@ int wdpm_create(wdpm_ctx **out, const wdpm_params *p) {
   x->comm = nullptr;
   x->d_dem = x->d_w[0] = x->d_w[1] = x->d_w[2] = nullptr;
   x->old = 2;
+  for (int i = 0; i < 3; i++) { x->d_zero[i] = nullptr; x->zero_valid[i] = false; }
+  x->tile_cap = x->tile_nstrips = x->tile_H = x->tile_nchunks = 0;
+  x->d_active = nullptr; x->h_active = nullptr;
+  x->tiles_launched = 0; x->sparse = false; x->stat_tiles = x->stat_active = 0;
+  { const char *e = getenv("WDPM_TILES"); x->tiles_mode = e ? atoi(e) : 1; }
   x->flush_pending = false;
   x->drain_owed = false;
   x->flush_thres = -__builtin_inf();
@@ -178,6 +206,14 @@ int wdpm_create(wdpm_ctx **out, const wdpm_params *p) {
   if (e == hipSuccess) e = hipMalloc(&x->d_dem32, x->cells * sizeof(int) + 64);
   if (e == hipSuccess) e = hipMalloc(&x->d_scal, 2 * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&x->d_bits, sizeof(unsigned long long));
+  {
+    /* tile flags: strips of 171 columns x chunks of >= 6 rows */
+    x->tile_cap = (x->g.ncp / 171 + 2) * (rows / 6 + 2);
+    for (int i = 0; i < 3 && e == hipSuccess; i++) e = hipMalloc(&x->d_zero[i], (size_t)x->tile_cap);
+    if (e == hipSuccess) e = hipMalloc(&x->d_active, sizeof(unsigned));
+    if (e == hipSuccess) e = hipHostMalloc(&x->h_active, sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemsetAsync(x->d_active, 0, sizeof(unsigned), x->stream);
+  }
   if (e == hipSuccess) e = hipHostMalloc(&x->h_pin, 4 * sizeof(double));
   if (e == hipSuccess) e = hipMemsetAsync(x->d_scal, 0, 2 * sizeof(double), x->stream);
   if (e == hipSuccess) e = hipMemsetAsync(x->d_w[2], 0, bytes, x->stream);   /* the snapshot before any block: zeros */
@@ -205,6 +241,9 @@ void wdpm_destroy(wdpm_ctx *x) {
   for (auto &ep : x->pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
   (void)hipFree(x->d_dem); (void)hipFree(x->d_w[0]); (void)hipFree(x->d_w[1]); (void)hipFree(x->d_w[2]);
   (void)hipFree(x->d_scal); (void)hipFree(x->d_bits); (void)hipFree(x->d_dem32); (void)hipFree(x->d_stat);
+  for (int i = 0; i < 3; i++) (void)hipFree(x->d_zero[i]);
+  (void)hipFree(x->d_active);
+  if (x->h_active) (void)hipHostFree(x->h_active);
   if (x->h_pin) (void)hipHostFree(x->h_pin);
   (void)hipFree(x->d_sum_approx); (void)hipFree(x->d_sum_i); (void)hipFree(x->d_sum_k); (void)hipFree(x->d_sum_flag);
   if (x->own_stream && x->stream) (void)hipStreamDestroy(x->stream);
@@ -294,6 +333,7 @@ int wdpm_upload_unpadded(wdpm_ctx *x, const double *dem, const double *water, co
   if (bind(x)) return 1;
   if (ensure_fresh_slot(x)) return 1;
   const int a = (x->cur + 1) % 3, b = (x->cur + 2) % 3;
+  x->zero_valid[a] = x->zero_valid[b] = false;
   const int R = x->g.R, C = x->g.C;
   int f0 = x->g.row0 - 1, f1 = x->g.row0 + x->g.rows - 2;     /* file rows behind the slab's padded rows */
   const int first = f0 < 0 ? 0 : f0, last = f1 > R - 1 ? R - 1 : f1;
@@ -374,7 +414,9 @@ int wdpm_download_unpadded(wdpm_ctx *x, int32_t file_row, int32_t nrows, int32_t
     return fail("wdpm_download_unpadded: rows outside the slab");
   if (nrows == 0) return 0;
   if (bind(x) || ensure_flushed(x)) return 1;
-  double *stage = x->d_w[free_slot(x)];
+  const int st = free_slot(x);
+  double *stage = x->d_w[st];
+  x->zero_valid[st] = false;
   HIP_TRY(wdpm_launch_unpad(x->d_w[x->cur], x->d_dem, x->g, file_row, nrows, mask_missing, stage, x->stream));
   HIP_TRY(hipMemcpyAsync(dst, stage, (size_t)nrows * x->g.C * sizeof(double), hipMemcpyDeviceToHost, x->stream));
   HIP_TRY(hipStreamSynchronize(x->stream));
@@ -413,6 +455,7 @@ int wdpm_upload_rows(wdpm_ctx *x, int32_t row, int32_t nrows, const double *src)
   if (row < 0 || nrows < 0 || row + nrows > x->g.rows || !src) return fail("wdpm_upload_rows: bad row range");
   if (bind(x)) return 1;
   if (ensure_private(x)) return 1;
+  x->zero_valid[x->cur] = false;
   HIP_TRY(hipMemcpyAsync(x->d_w[x->cur] + (size_t)row * x->g.ncp, src, (size_t)nrows * x->g.ncp * sizeof(double),
                          hipMemcpyHostToDevice, x->stream));
   return note_negzero(x, row, nrows);
@@ -460,6 +503,7 @@ int wdpm_copy_rows(wdpm_ctx *dst, int32_t dst_row, wdpm_ctx *src, int32_t src_ro
   if (bind(dst)) return 1;
   if (!dst->ev_copy[1]) HIP_TRY(hipEventCreateWithFlags(&dst->ev_copy[1], hipEventDisableTiming));
   HIP_TRY(hipStreamWaitEvent(dst->stream, src->ev_copy[0], 0));
+  if (tiles_touch(dst, dst->cur, dst_row, nrows)) return 1;       /* queued on dst's stream, ahead of the copy */
   const size_t bytes = (size_t)nrows * src->g.ncp * sizeof(double);
   double *d = dst->d_w[dst->cur] + (size_t)dst_row * dst->g.ncp;
   const double *s = src->d_w[src->cur] + (size_t)src_row * src->g.ncp;
@@ -475,6 +519,10 @@ int wdpm_get_option(wdpm_ctx *x, int32_t key, int64_t *value) {
   if (!value) return fail("wdpm_get_option: null argument");
   if (key == WDPM_OPT_SIGNED_ZERO_SAFE) *value = x->signed_zero_safe ? 1 : 0;
   else if (key == WDPM_OPT_DEM32) *value = x->code.q ? 1 : 0;
+  else if (key == WDPM_OPT_TILES) *value = x->tiles_mode;
+  else if (key == WDPM_OPT_TILES_SEEN) *value = x->stat_tiles;
+  else if (key == WDPM_OPT_TILES_WORKED) *value = x->stat_active;
+  else if (key == WDPM_OPT_SPARSE) *value = x->sparse ? 1 : 0;
   else return fail("wdpm_get_option: unknown option %d", key);
   return 0;
 }
@@ -486,6 +534,11 @@ int wdpm_set_option(wdpm_ctx *x, int32_t key, int64_t value) {
     /* switching it on is honoured only for a DEM that passed the device's bit-for-bit check */
     x->code.q = (value != 0 && x->dem32_encodable) ? x->d_dem32 : nullptr;
     x->code.force = value == 2;   /* 2: also on launches too small for the codes to pay (tests) */
+  } else if (key == WDPM_OPT_TILES) {
+    x->tiles_mode = value != 0;
+    x->zero_valid[0] = x->zero_valid[1] = x->zero_valid[2] = false;
+  } else if (key == WDPM_OPT_SPARSE) {
+    x->sparse = value != 0;
   } else {
     return fail("wdpm_set_option: unknown option %d", key);
   }
@@ -510,6 +563,7 @@ int wdpm_get_totaldrain(wdpm_ctx *x, double *v) {
 
 int wdpm_water_ptr(wdpm_ctx *x, void **ptr) {
   if (bind(x) || ensure_private(x)) return 1;   /* the caller may write through it */
+  x->zero_valid[x->cur] = false;
   *ptr = x->d_w[x->cur];
   return 0;
 }
@@ -526,6 +580,7 @@ int wdpm_begin_block(wdpm_ctx *x, double thres) {
   } else {
     const int t = x->cur == x->old ? free_slot(x) : x->old;
     HIP_TRY(wdpm_launch_flush_snapshot(x->d_w[x->cur], x->d_w[t], x->cells, thres, x->stream));
+    x->zero_valid[t] = false;
     x->old = t;
   }
   x->flush_thres = thres;
@@ -547,6 +602,7 @@ static int fold_timing(wdpm_ctx *x) {
 
 static int one_pass(wdpm_ctx *x, int oi, int oj) {
   if (ensure_private(x)) return 1;
+  x->zero_valid[x->cur] = false;
   HIP_TRY(wdpm_launch_pass(x->p.module, x->d_w[x->cur], x->d_dem, x->g, oi, oj, x->d_scal, x->stream));
   return 0;
 }
@@ -581,9 +637,24 @@ int wdpm_iterate(wdpm_ctx *x, int32_t n_iter) {
     if (x->kernel == WDPM_KERNEL_FUSED) {
       if (x->flush_pending && x->signed_zero_safe && ensure_flushed(x)) return 1;   /* no flush-on-load variant of that kernel */
       const int t = free_slot(x);
-      HIP_TRY(wdpm_launch_fused(x->p.module, x->d_w[x->cur], x->d_w[t], x->d_dem, x->code, x->g, x->p.chunk_rows,
+      TilePlan tp{x->d_zero[x->cur], x->d_zero[t], x->zero_valid[x->cur] ? 1 : 0, x->zero_valid[t] ? 1 : 0, x->d_active,
+                  x->tile_cap, x->tile_nstrips, x->tile_H, x->tile_nchunks, 0};
+      const bool track = x->tiles_mode != 0 && !x->signed_zero_safe;
+      /* sparse rasters march short chunks: the launch takes as long as its wettest tile */
+      const int chunk_rows = x->p.chunk_rows >= 3 ? x->p.chunk_rows : (track && x->sparse ? kSparseChunkRows : 0);
+      HIP_TRY(wdpm_launch_fused(x->p.module, x->d_w[x->cur], x->d_w[t], x->d_dem, x->code, x->g, chunk_rows,
                                 x->signed_zero_safe ? 1 : 0, x->flush_pending ? &x->flush_thres : nullptr,
-                                x->drain_owed ? 1 : 0, x->d_scal, x->stream));
+                                x->drain_owed ? 1 : 0, x->d_scal, x->stream, track ? &tp : nullptr));
+      if (track && tp.maintained) {
+        if (tp.nstrips != x->tile_nstrips || tp.H != x->tile_H || tp.nchunks != x->tile_nchunks) {
+          x->zero_valid[0] = x->zero_valid[1] = x->zero_valid[2] = false;     /* another tiling from here on */
+          x->tile_nstrips = tp.nstrips; x->tile_H = tp.H; x->tile_nchunks = tp.nchunks;
+        }
+        x->zero_valid[t] = true;
+        x->tiles_launched += (int64_t)tp.nstrips * tp.nchunks;
+      } else {
+        x->zero_valid[t] = false;
+      }
       x->cur = t;
       x->flush_pending = false;
       x->drain_owed = x->p.module == WDPM_DRAIN;     /* this iteration's drain(): owed to the next launch or reader */
@@ -650,6 +721,7 @@ int wdpm_iterate_overlapped(wdpm_ctx *x, int32_t n_iter, int32_t top_rows, int32
   }
   HIP_TRY(hipEventRecord(x->ev_join, x->side));
   x->pending_join = true;
+  x->zero_valid[t_slot] = false;   /* three windows, not the tiling the flags are kept for */
   x->cur = t_slot;
   x->flush_pending = false;
   x->launches += 3;
@@ -663,8 +735,22 @@ int wdpm_max_diff(wdpm_ctx *x, int32_t row_lo, int32_t row_hi, double *out) {
   /* the snapshot may hold the raster as it was BEFORE the block's flush: the kernel applies the flush as it reads */
   HIP_TRY(wdpm_launch_max_diff(x->d_w[x->cur], x->d_w[x->old], x->flush_thres, x->d_dem, x->g, row_lo, row_hi, x->d_bits, x->stream));
   HIP_TRY(hipMemcpyAsync(x->h_pin, x->d_bits, sizeof(double), hipMemcpyDeviceToHost, x->stream));
+  const bool look = x->tiles_launched > 0;
+  if (look) {
+    HIP_TRY(hipMemcpyAsync(x->h_active, x->d_active, sizeof(unsigned), hipMemcpyDeviceToHost, x->stream));
+    HIP_TRY(hipMemsetAsync(x->d_active, 0, sizeof(unsigned), x->stream));
+  }
   HIP_TRY(hipStreamSynchronize(x->stream));
   *out = x->h_pin[0];
+  if (look) {
+    /* once per block: how many tiles worked?  Mostly dry -> short chunks from the next block on (and back) */
+    const double frac = (double)*x->h_active / (double)x->tiles_launched;
+    x->stat_tiles += x->tiles_launched;
+    x->stat_active += *x->h_active;
+    x->tiles_launched = 0;
+    if (!x->sparse && frac < 0.30 && x->g.rows >= 4 * kSparseChunkRows) x->sparse = true;
+    else if (x->sparse && frac > 0.60) x->sparse = false;
+  }
   return 0;
 }
 

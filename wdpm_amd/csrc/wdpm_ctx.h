@@ -27,6 +27,16 @@ struct wdpm_ctx {
   int old;                      /* d_w[old] is oldwater (WDPMCL.c:1069-1073) - possibly still UNFLUSHED, see flush_pending */
   bool flush_pending;           /* wdpm_begin_block's threshold flush has not been applied yet: cur == old, and the next
                                    iteration launch applies it while loading (no pass over the raster of its own) */
+  /* dry-tile skipping (wdpm_kernels.h::TileFlags): one flag array per water raster, valid for one tiling */
+  unsigned char *d_zero[3];
+  bool zero_valid[3];           /* d_zero[i] describes d_w[i]'s current content (for tiling tile_*) */
+  int tile_cap, tile_nstrips, tile_H, tile_nchunks;
+  unsigned *d_active;           /* waves that did not skip since the last look */
+  unsigned *h_active;           /* pinned */
+  int64_t tiles_launched;       /* tiles of the flag-maintaining launches since the last look */
+  bool sparse;                  /* most tiles are dry: short chunks (96 rows), so that a wet tile is a short march */
+  int tiles_mode;               /* 1 on (default), 0 off (WDPM_TILES=0 / WDPM_OPT_TILES) */
+  int64_t stat_tiles, stat_active;   /* running totals for wdpm_get_option */
   bool drain_owed;              /* drain module: the last iteration's drain() (WDPMCL.c:1089) has not been applied to d_w[cur];
                                    the next iteration launch does it as it loads, anybody else asks ensure_drained() first */
   double flush_thres;           /* the threshold of the current block: the flush still owed to d_w[cur] (flush_pending)
@@ -61,5 +71,6 @@ struct wdpm_ctx {
 /* sets wdpm_last_error() of the calling thread and returns 1 */
 int wdpm_fail(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
 void wdpm_comm_release(wdpm_ctx *x);   /* wdpm_destroy's hook */
+int wdpm_tiles_touch(wdpm_ctx *x, int row, int nrows);   /* rows of the current raster written from outside: dry-tile flags */
 
 #endif

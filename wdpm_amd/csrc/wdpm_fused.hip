@@ -275,7 +275,8 @@ __global__ void __launch_bounds__(256, WDPM_FUSED_MIN_WAVES)
 fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout,
                        const double *__restrict__ dem, const DemCode code, const SlabGeom g, const int nstrips,
                        const int nitems, const int H, const int A0, const int out_last,
-                       double *__restrict__ totaldrain, const double thres, const int drain_owed) {
+                       double *__restrict__ totaldrain, const double thres, const int drain_owed,
+                       const TileFlags tf) {
   const int lane = threadIdx.x & 63;
   // Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2; placement is only a
   // speed matter, never correctness): give each XCD a contiguous run of work items so that the
@@ -298,6 +299,37 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
   int or_hi = A0 + H * (chunk + 1) + 1;
   if (or_hi > out_last) or_hi = out_last;
 
+  // Dry tiles (wdpm_kernels.h::TileFlags): if this tile and its eight neighbours hold nothing but +0.0 in `win`,
+  // the whole input window of this wave is dry - it lies inside those nine exact output blocks, because
+  // H >= 6 and the halo is 8 / 13 columns - no centre has water to give, and the output block is all +0.0.
+  // Then nothing is loaded, and nothing is stored either if `wout`'s block is known to hold zeros already.
+  if (tf.zout) {                                                       // wave-uniform
+    bool dry = tf.zin != nullptr;
+    if (dry) {
+#pragma unroll
+      for (int dc = -1; dc <= 1; dc++)
+#pragma unroll
+        for (int dsx = -1; dsx <= 1; dsx++) {
+          const int cc = chunk + dc, ss = strip + dsx;
+          if (cc >= 0 && cc < tf.nchunks && ss >= 0 && ss < nstrips) dry &= tf.zin[cc * nstrips + ss] != 0;
+        }
+    }
+    if (dry) {
+      const int tile = chunk * nstrips + strip;
+      if (!(tf.zout_known && tf.zout[tile] != 0)) {
+        const int hi = oc_hi < g.ncp - 1 ? oc_hi : g.ncp - 1;
+        for (int r = or_lo; r <= or_hi; r++)
+#pragma unroll
+          for (int k = 0; k < 3; k++) {
+            const int c = oc_lo + 64 * k + lane;
+            if (c <= hi) wout[(size_t)r * g.ncp + c] = 0.0;
+          }
+        if (lane == 0) tf.zout[tile] = 1;
+      }
+      return;
+    }
+  }
+  unsigned long long nzmask = 0;        // lanes that staged a value other than 0.0 (no -0.0 exists where tiles are tracked)
   const int colb = c0 + 3 * lane;
   // store side: after the LDS transpose, store instruction k = 0,1,2 writes the strip-relative
   // columns lo + 64k + lane of the exact output range [lo, hi].  Lanes past hi are clamped to hi:
@@ -508,7 +540,10 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
 #pragma unroll
       for (int i = 0; i < 3; i++)
 #pragma unroll
-        for (int j = 0; j < 3; j++) stage_lds[i * kStripIn + 3 * lane + j] = W[i][j];
+        for (int j = 0; j < 3; j++) {
+          stage_lds[i * kStripIn + 3 * lane + j] = W[i][j];
+          nzmask |= __ballot(W[i][j] != 0.0);            // one compare + a scalar OR per value
+        }
       __builtin_amdgcn_wave_barrier();
       // The rows requested at the top of this step must have landed before the compiler may touch
       // their registers (it copies them around the loop back-edge): wait here, where the only
@@ -533,6 +568,11 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
   else march(std::false_type{});
 
   if (MODULE == 2 && owner && lane == 0) *totaldrain = ds.td;
+  if (tf.zout && lane == 0) {
+    // every staged row went into the mask, the warm-up rows above the block included: a flag of 0 only says "unknown"
+    tf.zout[chunk * nstrips + strip] = nzmask ? 0 : 1;
+    atomicAdd(tf.active, 1u);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -886,16 +926,17 @@ static hipError_t dpp_selfcheck(hipStream_t s) {
 
 hipError_t wdpm_launch_fused(int module, const double *w_in, double *w_out, const double *dem, const DemCode &code,
                              const SlabGeom &g, int chunk_rows, int signed_zero_safe, const double *flush,
-                             int drain_owed, double *totaldrain, hipStream_t s) {
+                             int drain_owed, double *totaldrain, hipStream_t s, TilePlan *tiles) {
   return wdpm_launch_fused_rows(module, w_in, w_out, dem, code, g, 0, g.rows - 1, chunk_rows, signed_zero_safe, flush,
-                                drain_owed, totaldrain, s);
+                                drain_owed, totaldrain, s, tiles);
 }
 
 /* one iteration restricted to the output rows [A0 + 2 (0 when A0 == 0), out_last]; A0 % 3 == 0 */
 hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out, const double *dem,
                                   const DemCode &code, const SlabGeom &g, int A0, int out_last, int chunk_rows,
                                   int signed_zero_safe, const double *flush, int drain_owed, double *totaldrain,
-                                  hipStream_t s) {
+                                  hipStream_t s, TilePlan *tiles) {
+  if (tiles) tiles->maintained = 0;
   hipError_t e = dpp_selfcheck(s);
   if (e != hipSuccess) return e;
   if (A0 < 0 || A0 % 3 != 0 || out_last > g.rows - 1 || out_last < A0) return hipErrorInvalidValue;
@@ -971,7 +1012,18 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
   if (nchunks < 1) nchunks = 1;
   const int nitems = nstrips * nchunks;
   const dim3 grid(((nitems + 3) / 4 + 7) / 8 * 8), block(256);   // multiple of 8: see the XCD remap
-#define WDPM_LAUNCH(...) hipLaunchKernelGGL((fused_iteration_kernel<__VA_ARGS__>), grid, block, 0, s, w_in, w_out, dem, code, g, nstrips, nitems, H, A0, out_last, totaldrain, thres, module == 2 ? drain_owed : 0)
+  TileFlags tf{nullptr, nullptr, 0, nullptr, nchunks};
+  if (tiles && tiles->zout && fast && H >= 6 && A0 == 0 && out_last == g.rows - 1 && nitems <= tiles->capacity) {
+    // the flags describe one tiling: another chunk height or strip count makes the old ones meaningless
+    const bool same = tiles->nstrips == nstrips && tiles->H == H && tiles->nchunks == nchunks;
+    tf.zin = same && tiles->zin_valid ? tiles->zin : nullptr;
+    tf.zout = tiles->zout;
+    tf.zout_known = same && tiles->zout_valid;
+    tf.active = tiles->active;
+    tiles->nstrips = nstrips; tiles->H = H; tiles->nchunks = nchunks;
+    tiles->maintained = 1;
+  }
+#define WDPM_LAUNCH(...) hipLaunchKernelGGL((fused_iteration_kernel<__VA_ARGS__>), grid, block, 0, s, w_in, w_out, dem, code, g, nstrips, nitems, H, A0, out_last, totaldrain, thres, module == 2 ? drain_owed : 0, tf)
   if (module == 2 && fast) { if (flush) WDPM_LAUNCH(2, false, false, true); else WDPM_LAUNCH(2, false, false, false); }
   else if (module == 2) WDPM_LAUNCH(2, true, false, false);
   else if (dem32) { if (flush) WDPM_LAUNCH(0, false, true, true); else WDPM_LAUNCH(0, false, true, false); }

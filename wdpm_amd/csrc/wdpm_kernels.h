@@ -49,6 +49,29 @@ hipError_t wdpm_launch_seqsum_a(const double *w, const double *dem, size_t n, do
 hipError_t wdpm_launch_seqsum_b(const double *w, const double *dem, size_t n, const int *kexp, long long *isum,
                                 unsigned *tie, hipStream_t s);
 
+/* Dry-tile skipping (the reference skips dry centres cell by cell, WDPMCL.c:1099; basins are mostly dry land).
+ * A tile is the exact output block of one wave of the marching kernel (strip x chunk).  Per water raster one
+ * byte per tile: 1 = every cell of the block holds +0.0, 0 = unknown.  A wave whose tile and eight neighbours
+ * are flagged in the input raster has an all-dry input window: it loads nothing and its output block is all
+ * +0.0 - stored only if the output raster's own flag does not already say so.  Every other wave works as
+ * usual and leaves the flag of what it stored.  Only where no -0.0 depth exists (signed_zero_safe == 0). */
+struct TileFlags {               /* kernel argument */
+  const unsigned char *zin;      /* flags of w_in for this tiling, or nullptr (unknown: nobody skips) */
+  unsigned char *zout;           /* flags of w_out, written for every tile; nullptr = tiles not tracked in this launch */
+  int zout_known;                /* zout's current content describes w_out's current content */
+  unsigned *active;              /* += 1 per wave that did not skip */
+  int nchunks;
+};
+struct TilePlan {                /* host side of it, kept by the context per launch */
+  const unsigned char *zin;      /* in: flag arrays of the input / output raster */
+  unsigned char *zout;
+  int zin_valid, zout_valid;     /* in: they describe those rasters' current content (for the tiling below) */
+  unsigned *active;
+  int capacity;                  /* in: tiles each flag array has room for */
+  int nstrips, H, nchunks;       /* in: the tiling the flags were made for; out: the tiling of this launch */
+  int maintained;                /* out: this launch read / wrote the flags (marching kernel, whole slab, H >= 6) */
+};
+
 /* in place: dem <= miss (or NaN) -> +inf.  Every other kernel expects the DEM in this form. */
 hipError_t wdpm_launch_mark_nodata(double *dem, size_t cells, double miss, hipStream_t s);
 /* one colour pass, in place (reference kernels add/subtract/ddrain, runoff.cl:137-183) */
@@ -63,11 +86,11 @@ hipError_t wdpm_launch_pass(int module, double *w, const double *dem, const Slab
  * threshold flush, WDPMCL.c:1055-1065, riding on the first iteration; only with signed_zero_safe == 0) */
 hipError_t wdpm_launch_fused(int module, const double *w_in, double *w_out, const double *dem, const DemCode &code,
                              const SlabGeom &g, int chunk_rows, int signed_zero_safe, const double *flush,
-                             int drain_owed, double *totaldrain, hipStream_t s);
+                             int drain_owed, double *totaldrain, hipStream_t s, TilePlan *tiles = nullptr);
 hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out, const double *dem,
                                   const DemCode &code, const SlabGeom &g, int A0, int out_last, int chunk_rows,
                                   int signed_zero_safe, const double *flush, int drain_owed, double *totaldrain,
-                                  hipStream_t s);
+                                  hipStream_t s, TilePlan *tiles = nullptr);
 /* *flag |= 1 if any of the n doubles at p is -0.0 */
 hipError_t wdpm_launch_scan_negzero(const double *p, size_t n, unsigned long long *flag, hipStream_t s);
 /* drain() (WDPMCL.c:1859-1897) on the device */

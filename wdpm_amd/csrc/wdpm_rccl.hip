@@ -198,6 +198,8 @@ int wdpm_comm_exchange(wdpm_ctx *x, int32_t nsend, const wdpm_halo_op *sends, in
         return wdpm_fail("wdpm_comm_exchange: bad row range or peer");
   }
   HIP_TRY(hipSetDevice(x->p.device));
+  for (int i = 0; i < nrecv; i++)
+    if (wdpm_tiles_touch(x, recvs[i].row, recvs[i].nrows)) return 1;   /* received rows: those tiles are no longer known dry */
   double *w = x->d_w[x->cur];
   const size_t ncp = (size_t)x->g.ncp;
   NCCL_TRY(g_api.GroupStart());

@@ -261,11 +261,11 @@ class Group:
     uses with WDPM_GPUS=N.  devices may repeat (several slabs on one GPU: peer-copy halos)."""
 
     def __init__(self, lib: Lib, module, nrows: int, ncols: int, missingvalue: float, devices, exchange_every: int = 4,
-                 drainrow: int = 0, draincol: int = 0, kernel: int = 0):
+                 drainrow: int = 0, draincol: int = 0, kernel: int = 0, chunk_rows: int = 0):
         self.lib = lib
         m = MODULES[module] if isinstance(module, str) else module
         p = Params(module=m, nrows=nrows, ncols=ncols, drainrow=drainrow, draincol=draincol, slab_row0=0,
-                   slab_rows=0, device=0, kernel=kernel, chunk_rows=0, missingvalue=missingvalue)
+                   slab_rows=0, device=0, kernel=kernel, chunk_rows=chunk_rows, missingvalue=missingvalue)
         dev = (C.c_int32 * len(devices))(*devices)
         h = C.c_void_p()
         lib.check(lib.dll.wdpm_group_create(C.byref(h), C.byref(p), len(devices), dev, exchange_every))
