@@ -5,7 +5,7 @@ The DEM is rounded to 1e-4 m, so the DEM-code path applies as it does to real DE
 WDPM_FILL_PERCENT overrides the waves-per-SIMD choice)."""
 import sys, time
 import numpy as np
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import wdpm_amd
 R, C = int(sys.argv[1]), int(sys.argv[2]); iters = int(sys.argv[3]) if len(sys.argv) > 3 else 200
 only = sys.argv[4].split(",") if len(sys.argv) > 4 else None

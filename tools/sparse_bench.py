@@ -4,7 +4,7 @@ only in a few ponds.  Times blocks of iterations with dry-tile skipping on and o
     sparse_bench.py [n] [iterations per block] [blocks]"""
 import sys, time
 import numpy as np
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import wdpm_amd
 from wdpm_amd.capi import OPT_TILES, OPT_TILES_SEEN, OPT_TILES_WORKED, OPT_SPARSE
 
