@@ -20,7 +20,13 @@
 
 #include "wdpm_ctx.h"
 
-constexpr int kSparseChunkRows = 96;   /* chunk height of the iteration kernel once most tiles are dry */
+/* chunk height of the iteration kernel once most tiles are dry (WDPM_SPARSE_ROWS overrides: tuning) */
+static int sparse_chunk_rows() {
+  static int v = 0;
+  if (!v) { const char *e = getenv("WDPM_SPARSE_ROWS"); v = e && atoi(e) >= 6 ? atoi(e) / 3 * 3 : 96; }
+  return v;
+}
+#define kSparseChunkRows sparse_chunk_rows()
 
 static thread_local char g_err[512] = "";
 
