@@ -82,7 +82,9 @@ static int tiles_touch(wdpm_ctx *x, int slot, int row, int nrows) {
   if (c0 < 0) c0 = 0;
   if (c1 > x->tile_nchunks - 1) c1 = x->tile_nchunks - 1;
   if (c1 < c0) return 0;
-  HIP_TRY(hipMemsetAsync(x->d_zero[slot] + (size_t)c0 * x->tile_nstrips, 0, (size_t)(c1 - c0 + 1) * x->tile_nstrips, x->stream));
+  const size_t pitch = (size_t)x->tile_nstrips + 2;
+  HIP_TRY(hipMemset2DAsync(x->d_zero[slot] + (size_t)(c0 + 1) * pitch + 1, pitch, 0, (size_t)x->tile_nstrips, (size_t)(c1 - c0 + 1),
+                           x->stream));
   return 0;
 }
 
@@ -214,7 +216,7 @@ int wdpm_create(wdpm_ctx **out, const wdpm_params *p) {
   if (e == hipSuccess) e = hipMalloc(&x->d_bits, sizeof(unsigned long long));
   {
     /* tile flags: strips of 171 columns x chunks of >= 6 rows */
-    x->tile_cap = (x->g.ncp / 171 + 2) * (rows / 6 + 2);
+    x->tile_cap = (x->g.ncp / 171 + 4) * (rows / 6 + 4);
     for (int i = 0; i < 3 && e == hipSuccess; i++) e = hipMalloc(&x->d_zero[i], (size_t)x->tile_cap);
     if (e == hipSuccess) e = hipMalloc(&x->d_active, sizeof(unsigned));
     if (e == hipSuccess) e = hipHostMalloc(&x->h_active, sizeof(unsigned));
@@ -653,8 +655,12 @@ int wdpm_iterate(wdpm_ctx *x, int32_t n_iter) {
                                 x->drain_owed ? 1 : 0, x->d_scal, x->stream, track ? &tp : nullptr));
       if (track && tp.maintained) {
         if (tp.nstrips != x->tile_nstrips || tp.H != x->tile_H || tp.nchunks != x->tile_nchunks) {
-          x->zero_valid[0] = x->zero_valid[1] = x->zero_valid[2] = false;     /* another tiling from here on */
+          /* another tiling from here on: nothing known about any raster, and the flag arrays get their border of
+           * 1s for the new pitch (queued behind the launch, which wrote t's interior flags: only the other two) */
+          x->zero_valid[0] = x->zero_valid[1] = x->zero_valid[2] = false;
           x->tile_nstrips = tp.nstrips; x->tile_H = tp.H; x->tile_nchunks = tp.nchunks;
+          for (int i = 0; i < 3; i++)
+            if (i != t) HIP_TRY(hipMemsetAsync(x->d_zero[i], 1, (size_t)x->tile_cap, x->stream));
         }
         x->zero_valid[t] = true;
         x->tiles_launched += (int64_t)tp.nstrips * tp.nchunks;

@@ -303,19 +303,18 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
   // the whole input window of this wave is dry - it lies inside those nine exact output blocks, because
   // H >= 6 and the halo is 8 / 13 columns - no centre has water to give, and the output block is all +0.0.
   // Then nothing is loaded, and nothing is stored either if `wout`'s block is known to hold zeros already.
+  const int zpitch = nstrips + 2;                                      // flag arrays carry a border of 1s ("dry")
+  const int tile = (chunk + 1) * zpitch + strip + 1;
   if (tf.zout) {                                                       // wave-uniform
-    bool dry = tf.zin != nullptr;
-    if (dry) {
-#pragma unroll
-      for (int dc = -1; dc <= 1; dc++)
-#pragma unroll
-        for (int dsx = -1; dsx <= 1; dsx++) {
-          const int cc = chunk + dc, ss = strip + dsx;
-          if (cc >= 0 && cc < tf.nchunks && ss >= 0 && ss < nstrips) dry &= tf.zin[cc * nstrips + ss] != 0;
-        }
+    bool dry = false;
+    if (tf.zin) {
+      // nine unconditional loads in flight together (a bounds test per neighbour made nine dependent round trips)
+      const unsigned char *z = tf.zin + tile;
+      const unsigned f = z[-zpitch - 1] & z[-zpitch] & z[-zpitch + 1] & z[-1] & z[0] & z[1] & z[zpitch - 1] & z[zpitch] &
+                         z[zpitch + 1];
+      dry = f != 0;
     }
     if (dry) {
-      const int tile = chunk * nstrips + strip;
       if (!(tf.zout_known && tf.zout[tile] != 0)) {
         const int hi = oc_hi < g.ncp - 1 ? oc_hi : g.ncp - 1;
         for (int r = or_lo; r <= or_hi; r++)
@@ -570,7 +569,7 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
   if (MODULE == 2 && owner && lane == 0) *totaldrain = ds.td;
   if (tf.zout && lane == 0) {
     // every staged row went into the mask, the warm-up rows above the block included: a flag of 0 only says "unknown"
-    tf.zout[chunk * nstrips + strip] = nzmask ? 0 : 1;
+    tf.zout[tile] = nzmask ? 0 : 1;
     atomicAdd(tf.active, 1u);
   }
 }
@@ -1013,9 +1012,14 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
   const int nitems = nstrips * nchunks;
   const dim3 grid(((nitems + 3) / 4 + 7) / 8 * 8), block(256);   // multiple of 8: see the XCD remap
   TileFlags tf{nullptr, nullptr, 0, nullptr, nchunks};
-  if (tiles && tiles->zout && fast && H >= 6 && A0 == 0 && out_last == g.rows - 1 && nitems <= tiles->capacity) {
+  if (tiles && tiles->zout && fast && H >= 6 && A0 == 0 && out_last == g.rows - 1 &&
+      (nstrips + 2) * (nchunks + 2) <= tiles->capacity) {
     // the flags describe one tiling: another chunk height or strip count makes the old ones meaningless
     const bool same = tiles->nstrips == nstrips && tiles->H == H && tiles->nchunks == nchunks;
+    if (!same) {   /* new pitch: the output raster's flag array needs its border of 1s before the kernel fills the interior */
+      e = hipMemsetAsync(tiles->zout, 1, (size_t)tiles->capacity, s);
+      if (e != hipSuccess) return e;
+    }
     tf.zin = same && tiles->zin_valid ? tiles->zin : nullptr;
     tf.zout = tiles->zout;
     tf.zout_known = same && tiles->zout_valid;

@@ -54,7 +54,9 @@ hipError_t wdpm_launch_seqsum_b(const double *w, const double *dem, size_t n, co
  * byte per tile: 1 = every cell of the block holds +0.0, 0 = unknown.  A wave whose tile and eight neighbours
  * are flagged in the input raster has an all-dry input window: it loads nothing and its output block is all
  * +0.0 - stored only if the output raster's own flag does not already say so.  Every other wave works as
- * usual and leaves the flag of what it stored.  Only where no -0.0 depth exists (signed_zero_safe == 0). */
+ * usual and leaves the flag of what it stored.  Only where no -0.0 depth exists (signed_zero_safe == 0).
+ * Layout: (nchunks + 2) x (nstrips + 2) bytes, tile (chunk, strip) at [(chunk+1) * (nstrips+2) + strip + 1], the
+ * border always 1 (outside the slab there is no water), so that the nine flags are read without bounds tests. */
 struct TileFlags {               /* kernel argument */
   const unsigned char *zin;      /* flags of w_in for this tiling, or nullptr (unknown: nobody skips) */
   unsigned char *zout;           /* flags of w_out, written for every tile; nullptr = tiles not tracked in this launch */
