@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A mostly dry raster: synthetic n x n DEM, half of it NODATA (the lower-right triangle), water
 only in a few ponds.  Times blocks of iterations with dry-tile skipping on and off and checks that the rasters agree.
-    sparse_bench.py [n] [iterations per block] [blocks]"""
+    sparse_bench.py [n] [iterations per block] [blocks] [ponds]"""
 import sys, time
 import numpy as np
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,6 +11,7 @@ from wdpm_amd.capi import OPT_TILES, OPT_TILES_SEEN, OPT_TILES_WORKED, OPT_SPARS
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 blocks = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+ponds = int(sys.argv[4]) if len(sys.argv) > 4 else 12
 MISS = -99999.0
 lib = wdpm_amd.load_hip()
 dem = lib.synth_dem(n, n)
@@ -18,7 +19,7 @@ yy, xx = np.ogrid[0:n, 0:n]
 dem[(yy + xx) > n] = MISS                                    # ~50 % NODATA
 water = np.zeros((n, n))
 rng = np.random.default_rng(0)
-for _ in range(12):                                          # a dozen ponds of ~1 % of the side each
+for _ in range(ponds):                                       # a dozen ponds of ~1 % of the side each
     r, c = rng.integers(0, n // 2, 2)
     s = max(n // 100, 8)
     water[r:r + s, c:c + s] = 0.5
