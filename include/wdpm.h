@@ -114,6 +114,11 @@ int wdpm_drain_outlet(wdpm_ctx *ctx);
  * seeded with diff[0][0] of the slab's first row when row_lo==0 (WDPMCL.c:1239-1254).
  * row_lo=0,row_hi=slab_rows gives the reference value for a whole-raster context. */
 int wdpm_max_diff(wdpm_ctx *ctx, int32_t row_lo, int32_t row_hi, double *out);
+/* a hint: the caller is about to run the LAST wdpm_iterate / wdpm_iterate_overlapped of a block and will then ask
+ * wdpm_max_diff for exactly these rows.  The library may then reduce max|bigwater-oldwater| inside that call's last
+ * iteration launch, whose waves hold the final values anyway, instead of in a pass of its own over three rasters;
+ * wdpm_max_diff returns that value if nothing has written those rows in between.  Never changes a result. */
+int wdpm_expect_max_diff(wdpm_ctx *ctx, int32_t row_lo, int32_t row_hi);
 /* drain bookkeeping (WDPMCL.c:1257-1268): diffdrain = |totaldrain-olddrain| (NOT yet times
  * cellarea); final_sum = sum of bigwater over bigdem>missing in row-major order (NOT yet times
  * cellarea), bit-identical to the reference's sequential summation. */

@@ -474,6 +474,14 @@ def test_lazy_flush_and_snapshot_rotation(hip, oracle, module, kernel):
         [("iterate", 2), ("begin", t1), ("iterate", 4), ("begin", t2), ("maxdiff",), ("iterate", 1), ("maxdiff",), ("download",)],
         [("begin", t1), ("iterate_overlapped", 2, 12, 15), ("maxdiff",), ("download",)],
         [("begin", t1), ("outlet",), ("maxdiff",), ("download",)],
+        # the max-change reduction folded into the block's last iteration launch (wdpm_expect_max_diff)
+        [("begin", t1), ("expect", 0, R + 2), ("it", 5), ("maxdiff",), ("download",)],
+        [("begin", t1), ("expect", 0, R + 2), ("it", 1), ("maxdiff",), ("maxdiff",)],
+        [("begin", t1), ("expect", 6, 40), ("it", 4), ("maxdiff", 6, 40), ("maxdiff",), ("maxdiff", 6, 41)],
+        [("begin", t1), ("expect", 6, 40), ("iterate_overlapped", 3, 12, 15), ("maxdiff", 6, 40), ("download",)],
+        [("begin", t1), ("expect", 0, R + 2), ("it", 3), ("upload_rows", 9, rows), ("maxdiff",)],
+        [("begin", t1), ("expect", 0, R + 2), ("it", 3), ("it", 2), ("maxdiff",)],
+        [("it", 3), ("expect", 0, R + 2), ("it", 2), ("maxdiff",), ("begin", t2), ("expect", 0, R + 2), ("it", 2), ("maxdiff",)],
     ]
 
     def play(c, script):
@@ -481,8 +489,10 @@ def test_lazy_flush_and_snapshot_rotation(hip, oracle, module, kernel):
         for op in script:
             if op[0] == "begin":
                 c.begin_block(op[1])
+            elif op[0] == "expect":
+                c.expect_max_diff(op[1], op[2])
             elif op[0] == "maxdiff":
-                out.append(c.max_diff())
+                out.append(c.max_diff(*op[1:]))
             elif op[0] == "download":
                 out.append(c.download_water())
             elif op[0] == "upload_water":

@@ -88,6 +88,7 @@ SYMBOLS = {
     "wdpm_pass": (C.c_int, [_vp, C.c_int32, C.c_int32]),
     "wdpm_drain_outlet": (C.c_int, [_vp]),
     "wdpm_max_diff": (C.c_int, [_vp, C.c_int32, C.c_int32, _dp]),
+    "wdpm_expect_max_diff": (C.c_int, [_vp, C.c_int32, C.c_int32]),
     "wdpm_drain_stats": (C.c_int, [_vp, _dp, _dp]),
     "wdpm_volume_partial": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_double, _dp]),
     "wdpm_run_block": (C.c_int, [_vp, C.c_int32, C.c_double, _dp]),
@@ -325,6 +326,9 @@ class Context:
 
     def drain_outlet(self):
         self.lib.check(self.lib.dll.wdpm_drain_outlet(self._h))
+
+    def expect_max_diff(self, row_lo: int = 0, row_hi: int | None = None):
+        self.lib.check(self.lib.dll.wdpm_expect_max_diff(self._h, row_lo, self.slab.rows if row_hi is None else row_hi))
 
     def max_diff(self, row_lo: int = 0, row_hi: int | None = None) -> float:
         v = C.c_double()

@@ -74,6 +74,7 @@ static int bind(wdpm_ctx *x) {
 /* rows [row, row + nrows) of d_w[slot] are about to be (or have been) written by somebody other than the
  * iteration kernel: the tiles they touch are no longer known to be dry */
 static int tiles_touch(wdpm_ctx *x, int slot, int row, int nrows) {
+  if (slot == x->cur && nrows > 0 && row < x->md_hi && row + nrows > x->md_lo) x->md_valid = false;   /* rows of the folded max diff */
   if (!x->zero_valid[slot] || nrows <= 0) return 0;
   if (x->tile_H < 6 || x->tile_nchunks < 1) { x->zero_valid[slot] = false; return 0; }
   /* chunk i's block is rows [H*i + 2 (0 for i = 0), H*(i+1) + 1] */
@@ -115,6 +116,7 @@ static int ensure_flushed(wdpm_ctx *x) {
 
 /* in-place writers of d_w[cur] (pass kernels, drain(), partial uploads): the snapshot must survive */
 static int ensure_private(wdpm_ctx *x) {
+  x->md_valid = false;             /* whoever asks is about to write into the raster */
   if (ensure_drained(x)) return 1;
   if (x->cur != x->old) return 0;
   const int t = free_slot(x);
@@ -134,6 +136,7 @@ static int ensure_fresh_slot(wdpm_ctx *x) {
   if (ensure_flushed(x)) return 1;
   if (x->cur == x->old) x->cur = free_slot(x);
   x->zero_valid[x->cur] = false;
+  x->md_valid = false;
   return 0;
 }
 
@@ -190,6 +193,7 @@ int wdpm_create(wdpm_ctx **out, const wdpm_params *p) {
   x->tiles_launched = 0; x->sparse = false; x->stat_tiles = x->stat_active = 0;
   { const char *e = getenv("WDPM_TILES"); x->tiles_mode = e ? atoi(e) : 1; }
   x->flush_pending = false;
+  x->d_md = nullptr; x->md_hint = x->md_valid = false; x->md_lo = x->md_hi = 0;
   x->drain_owed = false;
   x->flush_thres = -__builtin_inf();
   x->d_scal = nullptr; x->d_bits = nullptr; x->h_pin = nullptr; x->d_stat = nullptr;
@@ -214,6 +218,7 @@ int wdpm_create(wdpm_ctx **out, const wdpm_params *p) {
   if (e == hipSuccess) e = hipMalloc(&x->d_dem32, x->cells * sizeof(int) + 64);
   if (e == hipSuccess) e = hipMalloc(&x->d_scal, 2 * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&x->d_bits, sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipMalloc(&x->d_md, sizeof(unsigned long long));
   {
     /* tile flags: strips of 171 columns x chunks of >= 6 rows */
     x->tile_cap = (x->g.ncp / 171 + 4) * (rows / 6 + 4);
@@ -251,6 +256,7 @@ void wdpm_destroy(wdpm_ctx *x) {
   (void)hipFree(x->d_scal); (void)hipFree(x->d_bits); (void)hipFree(x->d_dem32); (void)hipFree(x->d_stat);
   for (int i = 0; i < 3; i++) (void)hipFree(x->d_zero[i]);
   (void)hipFree(x->d_active);
+  (void)hipFree(x->d_md);
   if (x->h_active) (void)hipHostFree(x->h_active);
   if (x->h_pin) (void)hipHostFree(x->h_pin);
   (void)hipFree(x->d_sum_approx); (void)hipFree(x->d_sum_i); (void)hipFree(x->d_sum_k); (void)hipFree(x->d_sum_flag);
@@ -580,6 +586,7 @@ int wdpm_dem_ptr(wdpm_ctx *x, void **ptr) { *ptr = x->d_dem; return 0; }
 /* ---- block loop ------------------------------------------------------------------------- */
 int wdpm_begin_block(wdpm_ctx *x, double thres) {
   if (bind(x)) return 1;
+  x->md_valid = x->md_hint = false;
   if (ensure_flushed(x)) return 1;                       /* a flush still owed from a block that never iterated */
   if (x->kernel == WDPM_KERNEL_FUSED && !x->signed_zero_safe) {
     /* no pass over the raster: the current raster becomes the snapshot, the flush rides on the next launch's loads */
@@ -632,6 +639,8 @@ int wdpm_iterate(wdpm_ctx *x, int32_t n_iter) {
   if (n_iter < 0) return fail("wdpm_iterate: negative iteration count");
   if (n_iter == 0) return 0;
   if (bind(x)) return 1;
+  const bool fold = x->md_hint && x->kernel == WDPM_KERNEL_FUSED && x->p.module != WDPM_DRAIN && !x->signed_zero_safe;
+  x->md_hint = x->md_valid = false;
   /* stencil timing is opt-in (wdpm_timing_reset switches it on): two event records per call are a
    * measurable share of a small raster's iteration */
   EventPair ep{nullptr, nullptr};
@@ -650,9 +659,16 @@ int wdpm_iterate(wdpm_ctx *x, int32_t n_iter) {
       const bool track = x->tiles_mode != 0 && !x->signed_zero_safe;
       /* sparse rasters march short chunks: the launch takes as long as its wettest tile */
       const int chunk_rows = x->p.chunk_rows >= 3 ? x->p.chunk_rows : (track && x->sparse ? kSparseChunkRows : 0);
+      /* the block's last iteration also reduces max |w - oldw| over the rows the caller announced */
+      MaxDiffArgs md{nullptr, x->flush_thres, x->md_lo, x->md_hi, x->d_md};
+      if (fold && it == n_iter - 1) {
+        md.old = x->d_w[x->old];
+        HIP_TRY(hipMemsetAsync(x->d_md, 0, sizeof(unsigned long long), x->stream));
+      }
       HIP_TRY(wdpm_launch_fused(x->p.module, x->d_w[x->cur], x->d_w[t], x->d_dem, x->code, x->g, chunk_rows,
                                 x->signed_zero_safe ? 1 : 0, x->flush_pending ? &x->flush_thres : nullptr,
-                                x->drain_owed ? 1 : 0, x->d_scal, x->stream, track ? &tp : nullptr));
+                                x->drain_owed ? 1 : 0, x->d_scal, x->stream, track ? &tp : nullptr, md.old ? &md : nullptr));
+      if (md.old) x->md_valid = true;
       if (track && tp.maintained) {
         if (tp.nstrips != x->tile_nstrips || tp.H != x->tile_H || tp.nchunks != x->tile_nchunks) {
           /* another tiling from here on: nothing known about any raster, and the flag arrays get their border of
@@ -700,7 +716,10 @@ int wdpm_iterate_overlapped(wdpm_ctx *x, int32_t n_iter, int32_t top_rows, int32
                       (top_rows > 0 || bottom_rows > 0) && b_first - (t_last + 1) >= 24 && t_last < rows - 1 &&
                       b_first >= 2;
   if (!usable) return wdpm_iterate(x, n_iter);
+  const bool hint = x->md_hint;
+  x->md_hint = false;
   if (n_iter > 1 && wdpm_iterate(x, n_iter - 1)) return 1;
+  x->md_hint = hint;
   if (bind(x)) return 1;
   if (x->flush_pending && x->signed_zero_safe && ensure_flushed(x)) return 1;
   const int t_slot = free_slot(x);
@@ -708,6 +727,11 @@ int wdpm_iterate_overlapped(wdpm_ctx *x, int32_t n_iter, int32_t top_rows, int32
   double *w_out = x->d_w[t_slot];
   const int szs = x->signed_zero_safe ? 1 : 0;
   const double *flush = x->flush_pending ? &x->flush_thres : nullptr;
+  const bool fold = x->md_hint && !x->signed_zero_safe;     /* (usable: fused kernel, not the drain module) */
+  x->md_hint = x->md_valid = false;
+  MaxDiffArgs md{fold ? x->d_w[x->old] : nullptr, x->flush_thres, x->md_lo, x->md_hi, x->d_md};
+  const MaxDiffArgs *mdp = fold ? &md : nullptr;
+  if (fold) HIP_TRY(hipMemsetAsync(x->d_md, 0, sizeof(unsigned long long), x->stream));
   /* stencil timing of this iteration: from here on the main stream to the end of the interior launch
    * on the side stream (the longest of the three) */
   EventPair ep{nullptr, nullptr};
@@ -720,13 +744,13 @@ int wdpm_iterate_overlapped(wdpm_ctx *x, int32_t n_iter, int32_t top_rows, int32
   HIP_TRY(hipEventRecord(x->ev_fork, x->stream));               /* w_in is complete here */
   if (t_last >= 0)
     HIP_TRY(wdpm_launch_fused_rows(x->p.module, w_in, w_out, x->d_dem, x->code, x->g, 0, t_last, x->p.chunk_rows, szs, flush,
-                                   0, x->d_scal, x->stream));
+                                   0, x->d_scal, x->stream, nullptr, mdp));
   if (b_first < rows)
     HIP_TRY(wdpm_launch_fused_rows(x->p.module, w_in, w_out, x->d_dem, x->code, x->g, b_first - 2, rows - 1, x->p.chunk_rows,
-                                   szs, flush, 0, x->d_scal, x->stream));
+                                   szs, flush, 0, x->d_scal, x->stream, nullptr, mdp));
   HIP_TRY(hipStreamWaitEvent(x->side, x->ev_fork, 0));
   HIP_TRY(wdpm_launch_fused_rows(x->p.module, w_in, w_out, x->d_dem, x->code, x->g, t_last >= 0 ? t_last - 1 : 0,
-                                 b_first < rows ? b_first - 1 : rows - 1, x->p.chunk_rows, szs, flush, 0, x->d_scal, x->side));
+                                 b_first < rows ? b_first - 1 : rows - 1, x->p.chunk_rows, szs, flush, 0, x->d_scal, x->side, nullptr, mdp));
   if (x->timing) {
     HIP_TRY(hipEventRecord(ep.b, x->side));
     x->pending.push_back(ep);
@@ -734,9 +758,18 @@ int wdpm_iterate_overlapped(wdpm_ctx *x, int32_t n_iter, int32_t top_rows, int32
   HIP_TRY(hipEventRecord(x->ev_join, x->side));
   x->pending_join = true;
   x->zero_valid[t_slot] = false;   /* three windows, not the tiling the flags are kept for */
+  if (fold) x->md_valid = true;
   x->cur = t_slot;
   x->flush_pending = false;
   x->launches += 3;
+  return 0;
+}
+
+int wdpm_expect_max_diff(wdpm_ctx *x, int32_t row_lo, int32_t row_hi) {
+  if (row_lo < 0 || row_hi > x->g.rows || row_lo > row_hi) return fail("wdpm_expect_max_diff: bad row range");
+  x->md_hint = true;
+  x->md_lo = row_lo;
+  x->md_hi = row_hi;
   return 0;
 }
 
@@ -744,8 +777,10 @@ int wdpm_max_diff(wdpm_ctx *x, int32_t row_lo, int32_t row_hi, double *out) {
   if (row_lo < 0 || row_hi > x->g.rows || row_lo > row_hi || !out) return fail("wdpm_max_diff: bad row range");
   if (bind(x)) return 1;
   if (ensure_flushed(x)) return 1;
+  const bool folded = x->md_valid && x->md_lo == row_lo && x->md_hi == row_hi;   /* the last iteration launch already reduced it */
   /* the snapshot may hold the raster as it was BEFORE the block's flush: the kernel applies the flush as it reads */
-  HIP_TRY(wdpm_launch_max_diff(x->d_w[x->cur], x->d_w[x->old], x->flush_thres, x->d_dem, x->g, row_lo, row_hi, x->d_bits, x->stream));
+  if (folded) HIP_TRY(hipMemcpyAsync(x->d_bits, x->d_md, sizeof(unsigned long long), hipMemcpyDeviceToDevice, x->stream));
+  else HIP_TRY(wdpm_launch_max_diff(x->d_w[x->cur], x->d_w[x->old], x->flush_thres, x->d_dem, x->g, row_lo, row_hi, x->d_bits, x->stream));
   HIP_TRY(hipMemcpyAsync(x->h_pin, x->d_bits, sizeof(double), hipMemcpyDeviceToHost, x->stream));
   const bool look = x->tiles_launched > 0;
   if (look) {
@@ -864,6 +899,7 @@ void wdpm_host_free(void *ptr) {
 
 int wdpm_run_block(wdpm_ctx *x, int32_t n_iter, double thres, double *max_diff) {
   if (wdpm_begin_block(x, thres)) return 1;
+  if (wdpm_expect_max_diff(x, 0, x->g.rows)) return 1;
   if (wdpm_iterate(x, n_iter)) return 1;
   return wdpm_max_diff(x, 0, x->g.rows, max_diff);
 }

@@ -37,6 +37,10 @@ struct wdpm_ctx {
   bool sparse;                  /* most tiles are dry: short chunks (96 rows), so that a wet tile is a short march */
   int tiles_mode;               /* 1 on (default), 0 off (WDPM_TILES=0 / WDPM_OPT_TILES) */
   int64_t stat_tiles, stat_active;   /* running totals for wdpm_get_option */
+  /* max |w - oldw| folded into the last iteration launch of a block (wdpm_expect_max_diff) */
+  unsigned long long *d_md;     /* its reduction cell */
+  bool md_hint, md_valid;       /* the next wdpm_iterate may fold it / d_md holds the value for rows [md_lo, md_hi) */
+  int md_lo, md_hi;
   bool drain_owed;              /* drain module: the last iteration's drain() (WDPMCL.c:1089) has not been applied to d_w[cur];
                                    the next iteration launch does it as it loads, anybody else asks ensure_drained() first */
   double flush_thres;           /* the threshold of the current block: the flush still owed to d_w[cur] (flush_pending)

@@ -270,13 +270,13 @@ struct Prefetched {
   int qe[3][3];
 };
 
-template <int MODULE, bool SZ_SAFE, bool DEM32, bool FLUSH = false>
+template <int MODULE, bool SZ_SAFE, bool DEM32, bool FLUSH = false, bool MD = false>
 __global__ void __launch_bounds__(256, WDPM_FUSED_MIN_WAVES)
 fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout,
                        const double *__restrict__ dem, const DemCode code, const SlabGeom g, const int nstrips,
                        const int nitems, const int H, const int A0, const int out_last,
                        double *__restrict__ totaldrain, const double thres, const int drain_owed,
-                       const TileFlags tf) {
+                       const TileFlags tf, const MaxDiffArgs md) {
   const int lane = threadIdx.x & 63;
   // Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2; placement is only a
   // speed matter, never correctness): give each XCD a contiguous run of work items so that the
@@ -329,6 +329,7 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
     }
   }
   unsigned long long nzmask = 0;        // lanes that staged a value other than 0.0 (no -0.0 exists where tiles are tracked)
+  double md_max = 0.0;                  // MD: this lane's max |w - oldw| over the cells of its output block (WDPMCL.c:1239-1254)
   const int colb = c0 + 3 * lane;
   // store side: after the LDS transpose, store instruction k = 0,1,2 writes the strip-relative
   // columns lo + 64k + lane of the exact output range [lo, hi].  Lanes past hi are clamped to hi:
@@ -536,6 +537,28 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
       // private LDS slice (no barrier: a wave's LDS operations complete in order) so that every
       // store instruction writes 512 contiguous bytes, streamed past the L2 (non-temporal); the
       // stores themselves are issued by store_rows() at the top of the next step.
+      if (MD) {
+        // rows 3n-4 .. 3n-2 are final: their part of the block's max-change reduction, against the snapshot
+        // (which may still be owed the block's flush: applied as it is read).  Only cells of this wave's own
+        // output block, of the rows asked for, with bigdem > missingvalue - plus the reference's seed cell [0][0].
+        const int hi = oc_hi < g.ncp - 1 ? oc_hi : g.ncp - 1;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          const int r = rbase + i;
+          const bool row_in = r >= or_lo && r <= or_hi && r >= md.row_lo && r < md.row_hi;     // wave-uniform
+          const int rc = r < 0 ? 0 : (r < g.rows ? r : g.rows - 1);
+#pragma unroll
+          for (int j = 0; j < 3; j++) {
+            const int c = colb + j;
+            const int cc = c < g.ncp ? c : g.ncp - 1;
+            double o = md.old[(size_t)rc * pitch + cc];
+            o = o < md.thres ? 0.0 : o;                                                         // :1059-1062
+            const double dd = __builtin_fabs(W[i][j] - o);                                      // :1241
+            const bool cell = row_in & (c >= oc_lo) & (c <= hi) & ((D[i][j] < WDPM_INF) | ((r == 0) & (c == 0)));
+            md_max = (cell & (dd > md_max)) ? dd : md_max;                                        // :1245-1254
+          }
+        }
+      }
 #pragma unroll
       for (int i = 0; i < 3; i++)
 #pragma unroll
@@ -567,6 +590,14 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
   else march(std::false_type{});
 
   if (MODULE == 2 && owner && lane == 0) *totaldrain = ds.td;
+  if (MD) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const double o = __shfl_xor(md_max, off, 64);
+      md_max = o > md_max ? o : md_max;
+    }
+    if (lane == 0 && md_max > 0.0) atomicMax(md.bits, (unsigned long long)__double_as_longlong(md_max));   // >= 0: order-preserving
+  }
   if (tf.zout && lane == 0) {
     // every staged row went into the mask, the warm-up rows above the block included: a flag of 0 only says "unknown"
     tf.zout[tile] = nzmask ? 0 : 1;
@@ -925,17 +956,19 @@ static hipError_t dpp_selfcheck(hipStream_t s) {
 
 hipError_t wdpm_launch_fused(int module, const double *w_in, double *w_out, const double *dem, const DemCode &code,
                              const SlabGeom &g, int chunk_rows, int signed_zero_safe, const double *flush,
-                             int drain_owed, double *totaldrain, hipStream_t s, TilePlan *tiles) {
+                             int drain_owed, double *totaldrain, hipStream_t s, TilePlan *tiles, const MaxDiffArgs *md) {
   return wdpm_launch_fused_rows(module, w_in, w_out, dem, code, g, 0, g.rows - 1, chunk_rows, signed_zero_safe, flush,
-                                drain_owed, totaldrain, s, tiles);
+                                drain_owed, totaldrain, s, tiles, md);
 }
 
 /* one iteration restricted to the output rows [A0 + 2 (0 when A0 == 0), out_last]; A0 % 3 == 0 */
 hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out, const double *dem,
                                   const DemCode &code, const SlabGeom &g, int A0, int out_last, int chunk_rows,
                                   int signed_zero_safe, const double *flush, int drain_owed, double *totaldrain,
-                                  hipStream_t s, TilePlan *tiles) {
+                                  hipStream_t s, TilePlan *tiles, const MaxDiffArgs *md) {
   if (tiles) tiles->maintained = 0;
+  const bool fold_md = md && md->old && module != 2 && !signed_zero_safe;
+  if (md && md->old && !fold_md) return hipErrorInvalidValue;     /* the caller asks only where a folding variant exists */
   hipError_t e = dpp_selfcheck(s);
   if (e != hipSuccess) return e;
   if (A0 < 0 || A0 % 3 != 0 || out_last > g.rows - 1 || out_last < A0) return hipErrorInvalidValue;
@@ -958,7 +991,7 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
     int nch = (out_last - A0 - 1 + 2) / 3;
     if (nch < 1) nch = 1;
     const long long items = (long long)nstr * nch;
-    if (env_tri && !signed_zero_safe && chunk_rows < 3 && (items <= tri_slots || env_tri == 2)) {
+    if (env_tri && !signed_zero_safe && !fold_md && chunk_rows < 3 && (items <= tri_slots || env_tri == 2)) {
       const dim3 tgrid(((unsigned)((items + 3) / 4) + 7) / 8 * 8), tblock(256);
 #define WDPM_TRI_LAUNCH(M, F) hipLaunchKernelGGL((tri_iteration_kernel<M, F>), tgrid, tblock, 0, s, w_in, w_out, dem, g, nstr, (int)items, A0, out_last, totaldrain, thres, module == 2 ? drain_owed : 0)
       if (module == 2) { if (flush) WDPM_TRI_LAUNCH(2, true); else WDPM_TRI_LAUNCH(2, false); }
@@ -1027,12 +1060,18 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
     tiles->nstrips = nstrips; tiles->H = H; tiles->nchunks = nchunks;
     tiles->maintained = 1;
   }
-#define WDPM_LAUNCH(...) hipLaunchKernelGGL((fused_iteration_kernel<__VA_ARGS__>), grid, block, 0, s, w_in, w_out, dem, code, g, nstrips, nitems, H, A0, out_last, totaldrain, thres, module == 2 ? drain_owed : 0, tf)
-  if (module == 2 && fast) { if (flush) WDPM_LAUNCH(2, false, false, true); else WDPM_LAUNCH(2, false, false, false); }
-  else if (module == 2) WDPM_LAUNCH(2, true, false, false);
-  else if (dem32) { if (flush) WDPM_LAUNCH(0, false, true, true); else WDPM_LAUNCH(0, false, true, false); }
-  else if (fast) { if (flush) WDPM_LAUNCH(0, false, false, true); else WDPM_LAUNCH(0, false, false, false); }
-  else WDPM_LAUNCH(0, true, false, false);
+  const MaxDiffArgs mda = fold_md ? *md : MaxDiffArgs{nullptr, 0.0, 0, 0, nullptr};
+  if (fold_md) tf = TileFlags{nullptr, nullptr, 0, nullptr, nchunks};   /* every wave must look at its block: no skipping in this launch */
+  if (fold_md && tiles) tiles->maintained = 0;
+#define WDPM_LAUNCH(...) hipLaunchKernelGGL((fused_iteration_kernel<__VA_ARGS__>), grid, block, 0, s, w_in, w_out, dem, code, g, nstrips, nitems, H, A0, out_last, totaldrain, thres, module == 2 ? drain_owed : 0, tf, mda)
+#define WDPM_LAUNCH_FM(M, Z, D32) do { if (fold_md) { if (flush) WDPM_LAUNCH(M, Z, D32, true, true); else WDPM_LAUNCH(M, Z, D32, false, true); } \
+                                       else { if (flush) WDPM_LAUNCH(M, Z, D32, true, false); else WDPM_LAUNCH(M, Z, D32, false, false); } } while (0)
+  if (module == 2 && fast) { if (flush) WDPM_LAUNCH(2, false, false, true, false); else WDPM_LAUNCH(2, false, false, false, false); }
+  else if (module == 2) WDPM_LAUNCH(2, true, false, false, false);
+  else if (dem32) WDPM_LAUNCH_FM(0, false, true);
+  else if (fast) WDPM_LAUNCH_FM(0, false, false);
+  else WDPM_LAUNCH(0, true, false, false, false);
+#undef WDPM_LAUNCH_FM
 #undef WDPM_LAUNCH
   return hipGetLastError();
 }

@@ -74,6 +74,15 @@ struct TilePlan {                /* host side of it, kept by the context per lau
   int maintained;                /* out: this launch read / wrote the flags (marching kernel, whole slab, H >= 6) */
 };
 
+/* max |w - oldw| folded into an iteration launch (the last one of a block): the waves have the final values in
+ * registers anyway; one more raster read (the snapshot) instead of a pass over three.  old == nullptr: off. */
+struct MaxDiffArgs {
+  const double *old;             /* the snapshot, possibly still owed the threshold flush `thres` (applied as read) */
+  double thres;
+  int row_lo, row_hi;            /* slab rows [row_lo, row_hi) */
+  unsigned long long *bits;      /* atomicMax of the bit image of the (non-negative) maximum; zeroed by the caller */
+};
+
 /* in place: dem <= miss (or NaN) -> +inf.  Every other kernel expects the DEM in this form. */
 hipError_t wdpm_launch_mark_nodata(double *dem, size_t cells, double miss, hipStream_t s);
 /* one colour pass, in place (reference kernels add/subtract/ddrain, runoff.cl:137-183) */
@@ -88,11 +97,12 @@ hipError_t wdpm_launch_pass(int module, double *w, const double *dem, const Slab
  * threshold flush, WDPMCL.c:1055-1065, riding on the first iteration; only with signed_zero_safe == 0) */
 hipError_t wdpm_launch_fused(int module, const double *w_in, double *w_out, const double *dem, const DemCode &code,
                              const SlabGeom &g, int chunk_rows, int signed_zero_safe, const double *flush,
-                             int drain_owed, double *totaldrain, hipStream_t s, TilePlan *tiles = nullptr);
+                             int drain_owed, double *totaldrain, hipStream_t s, TilePlan *tiles = nullptr,
+                             const MaxDiffArgs *md = nullptr);
 hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out, const double *dem,
                                   const DemCode &code, const SlabGeom &g, int A0, int out_last, int chunk_rows,
                                   int signed_zero_safe, const double *flush, int drain_owed, double *totaldrain,
-                                  hipStream_t s, TilePlan *tiles = nullptr);
+                                  hipStream_t s, TilePlan *tiles = nullptr, const MaxDiffArgs *md = nullptr);
 /* *flag |= 1 if any of the n doubles at p is -0.0 */
 hipError_t wdpm_launch_scan_negzero(const double *p, size_t n, unsigned long long *flag, hipStream_t s);
 /* drain() (WDPMCL.c:1859-1897) on the device */

@@ -357,7 +357,13 @@ static int exchange_now(wdpm_rank *r) {
 /* ---- the block loop pieces (WDPMCL.c:1055-1125, 1239-1268) ------------------------------------- */
 int wdpm_rank_begin_block(wdpm_rank *r, double thres) { return wdpm_begin_block(r->c, thres); }
 
-int wdpm_rank_iterate(wdpm_rank *r, int32_t n_iter) {
+static int rank_iterate(wdpm_rank *r, int32_t n_iter, int block_end);
+static void owned_rows(const wdpm_rank *r, int *lo, int *hi);
+
+int wdpm_rank_iterate(wdpm_rank *r, int32_t n_iter) { return rank_iterate(r, n_iter, 0); }
+
+/* block_end: a wdpm_rank_max_diff follows - the last launch call may fold the reduction over the owned rows */
+static int rank_iterate(wdpm_rank *r, int32_t n_iter, int block_end) {
   if (n_iter < 0) return rb_fail("wdpm_rank_iterate: negative iteration count");
   int done = 0;
   while (done < n_iter) {
@@ -368,6 +374,11 @@ int wdpm_rank_iterate(wdpm_rank *r, int32_t n_iter) {
     }
     const int step = r->n == 1 ? n_iter - done : (room < n_iter - done ? room : n_iter - done);
     const double t0 = now_s();
+    if (block_end && done + step == n_iter) {
+      int lo, hi;
+      owned_rows(r, &lo, &hi);
+      if (wdpm_expect_max_diff(r->c, lo, hi)) return 1;
+    }
     if (r->overlap && step == room) {
       /* this step ends a group of k and an exchange follows: produce the rows the neighbours need
        * first, so that the transfer overlaps the interior rows of the last iteration */
@@ -401,7 +412,7 @@ int wdpm_rank_max_diff(wdpm_rank *r, double *max_diff) {
 
 int wdpm_rank_run_block(wdpm_rank *r, int32_t n_iter, double thres, double *max_diff) {
   if (wdpm_rank_begin_block(r, thres)) return 1;
-  if (wdpm_rank_iterate(r, n_iter)) return 1;
+  if (rank_iterate(r, n_iter, 1)) return 1;
   return wdpm_rank_max_diff(r, max_diff);
 }
 
