@@ -750,7 +750,8 @@ int wdpm_iterate_overlapped(wdpm_ctx *x, int32_t n_iter, int32_t top_rows, int32
                                    szs, flush, 0, x->d_scal, x->stream, nullptr, mdp));
   HIP_TRY(hipStreamWaitEvent(x->side, x->ev_fork, 0));
   HIP_TRY(wdpm_launch_fused_rows(x->p.module, w_in, w_out, x->d_dem, x->code, x->g, t_last >= 0 ? t_last - 1 : 0,
-                                 b_first < rows ? b_first - 1 : rows - 1, x->p.chunk_rows, szs, flush, 0, x->d_scal, x->side, nullptr, mdp));
+                                 b_first < rows ? b_first - 1 : rows - 1, x->p.chunk_rows, szs, flush, 0, x->d_scal, x->side, nullptr, mdp,
+                                 x->comm ? 8 : 0));   /* 8 of 256 CUs stay free for the RCCL kernels of the refresh that follows */
   if (x->timing) {
     HIP_TRY(hipEventRecord(ep.b, x->side));
     x->pending.push_back(ep);

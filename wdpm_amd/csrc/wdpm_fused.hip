@@ -965,7 +965,7 @@ hipError_t wdpm_launch_fused(int module, const double *w_in, double *w_out, cons
 hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out, const double *dem,
                                   const DemCode &code, const SlabGeom &g, int A0, int out_last, int chunk_rows,
                                   int signed_zero_safe, const double *flush, int drain_owed, double *totaldrain,
-                                  hipStream_t s, TilePlan *tiles, const MaxDiffArgs *md) {
+                                  hipStream_t s, TilePlan *tiles, const MaxDiffArgs *md, int leave_cus) {
   if (tiles) tiles->maintained = 0;
   const bool fold_md = md && md->old && module != 2 && !signed_zero_safe;
   if (md && md->old && !fold_md) return hipErrorInvalidValue;     /* the caller asks only where a folding variant exists */
@@ -1036,6 +1036,11 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
     if (module == 2 && (long long)(out_last - A0 + 1) * nstrips >= 18LL * slots) pct = 100;
     if (env_pct > 0) pct = env_pct;
     if (pct > 0 && pct < 100) slots = slots * pct / 100;
+    if (leave_cus > 0) {                               // room for somebody else's kernels (see wdpm_kernels.h)
+      int dev = 0, cus = 256;
+      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      if (leave_cus < cus / 2) slots = (int)((long long)slots * (cus - leave_cus) / cus);
+    }
   }
   const int wrows = out_last - A0 + 1;                       // rows of this launch's window
   const int H = pick_chunk_rows(wrows, nstrips, chunk_rows, slots);

@@ -102,7 +102,11 @@ hipError_t wdpm_launch_fused(int module, const double *w_in, double *w_out, cons
 hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out, const double *dem,
                                   const DemCode &code, const SlabGeom &g, int A0, int out_last, int chunk_rows,
                                   int signed_zero_safe, const double *flush, int drain_owed, double *totaldrain,
-                                  hipStream_t s, TilePlan *tiles = nullptr, const MaxDiffArgs *md = nullptr);
+                                  hipStream_t s, TilePlan *tiles = nullptr, const MaxDiffArgs *md = nullptr,
+                                  int leave_cus = 0);
+/* leave_cus: size the launch as if the chip had that many compute units fewer - the interior launch of an overlapped
+ * iteration leaves room for the RCCL send/recv kernels queued beside it (a launch otherwise fills every slot for its
+ * whole duration, and the transfer would start only when the first waves retire) */
 /* *flag |= 1 if any of the n doubles at p is -0.0 */
 hipError_t wdpm_launch_scan_negzero(const double *p, size_t n, unsigned long long *flag, hipStream_t s);
 /* drain() (WDPMCL.c:1859-1897) on the device */
