@@ -698,8 +698,7 @@ template <int MODULE, bool FLUSH>
 __global__ void __launch_bounds__(256, 2)
 tri_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout, const double *__restrict__ dem,
                      const SlabGeom g, const int nstrips, const int nitems, const int A0, const int out_last,
-                     double *__restrict__ totaldrain, const double thres, const int flags) {
-  const int drain_owed = flags & 1;         // bit 8: non-temporal stores (WDPM_TRI_NT=1, A/B only)
+                     double *__restrict__ totaldrain, const double thres, const int drain_owed) {
   const int lane = threadIdx.x & 63;
   const int vb = (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8;       // XCD-contiguous items
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -876,12 +875,7 @@ tri_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout, 
 #pragma unroll
     for (int j = 0; j < 3; j++) {
       const int c = colb + j;
-      if (c >= oc_lo && c <= oc_hi) {
-        // a raster this small lives in the cache hierarchy between launches: ordinary stores (the marching kernel
-        // streams past the L2 because its rasters never fit)
-        if (flags & 0x100) __builtin_nontemporal_store(W[i][j], wout + (size_t)r * pitch + c);
-        else wout[(size_t)r * pitch + c] = W[i][j];
-      }
+      if (c >= oc_lo && c <= oc_hi) __builtin_nontemporal_store(W[i][j], wout + (size_t)r * pitch + c);
     }
   }
   if (MODULE == 2 && owner && lane == 0) *totaldrain = ds.td;
@@ -999,10 +993,7 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
     const long long items = (long long)nstr * nch;
     if (env_tri && !signed_zero_safe && !fold_md && chunk_rows < 3 && (items <= tri_slots || env_tri == 2)) {
       const dim3 tgrid(((unsigned)((items + 3) / 4) + 7) / 8 * 8), tblock(256);
-      static int env_nt = -1;
-      if (env_nt < 0) { const char *t = getenv("WDPM_TRI_NT"); env_nt = t ? atoi(t) : 0; }
-      const int owed = (module == 2 ? (drain_owed ? 1 : 0) : 0) | (env_nt ? 0x100 : 0);
-#define WDPM_TRI_LAUNCH(M, F) hipLaunchKernelGGL((tri_iteration_kernel<M, F>), tgrid, tblock, 0, s, w_in, w_out, dem, g, nstr, (int)items, A0, out_last, totaldrain, thres, owed)
+#define WDPM_TRI_LAUNCH(M, F) hipLaunchKernelGGL((tri_iteration_kernel<M, F>), tgrid, tblock, 0, s, w_in, w_out, dem, g, nstr, (int)items, A0, out_last, totaldrain, thres, module == 2 ? drain_owed : 0)
       if (module == 2) { if (flush) WDPM_TRI_LAUNCH(2, true); else WDPM_TRI_LAUNCH(2, false); }
       else { if (flush) WDPM_TRI_LAUNCH(0, true); else WDPM_TRI_LAUNCH(0, false); }
 #undef WDPM_TRI_LAUNCH
