@@ -3,7 +3,7 @@
 curve (a projection - the halo transfers themselves need a second GPU).  For N = 1, 2, 4, 8 the slab of the middle
 rank of the 16384^2 add workload (halos for k iterations on both sides) runs k-1 plain iterations and one overlapped
 iteration (three launches, the interior on the side stream), exactly as wdpm_rank_iterate queues them.
-    scale_projection.py [size] [k] [groups]"""
+    scale_projection.py [size] [k] [groups] [plain]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,6 +13,7 @@ from wdpm_amd.rowblock import partition
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 groups = int(sys.argv[3]) if len(sys.argv) > 3 else 50
+plain = len(sys.argv) > 4 and sys.argv[4] == "plain"        # no overlapped iteration: the refresh would wait for the whole group
 MISS = -99999.0
 lib = wdpm_amd.load_hip()
 dem = lib.synth_dem(n, n)
@@ -29,7 +30,7 @@ for N in (1, 2, 4, 8):
         top = s.lo + slabs[s.rank - 1].down if s.rank > 0 else 0
         bottom = s.rows - (s.hi - slabs[s.rank + 1].up) if s.rank < N - 1 else 0
         def group():
-            if N > 1:
+            if N > 1 and not plain:
                 c.iterate_overlapped(k, top, bottom)
             else:
                 c.iterate(k)
