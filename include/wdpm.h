@@ -167,6 +167,10 @@ int wdpm_synchronize(wdpm_ctx *ctx);
  * context's stream): number of stencil launches and their summed duration in ms. */
 int wdpm_timing_reset(wdpm_ctx *ctx);
 int wdpm_timing_get(wdpm_ctx *ctx, int64_t *launches, double *ms);
+/* the same restricted to the launches of each wdpm_iterate call between its first and its last (calls of >= 3
+ * iterations): the first launch of a block may be the flush-on-load variant of the kernel and the last the max-diff
+ * variant, so this is the kernel a profiler lists as the dominant one.  0 launches if there were none. */
+int wdpm_timing_get_steady(wdpm_ctx *ctx, int64_t *launches, double *ms);
 
 /* copy `nrows` rows of the CURRENT water raster from slab-local row `src_row` of `src` to row
  * `dst_row` of `dst` (same raster width).  Device to device on the HIP back-end (peer copy over

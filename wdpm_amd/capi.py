@@ -98,6 +98,7 @@ SYMBOLS = {
     "wdpm_synchronize": (C.c_int, [_vp]),
     "wdpm_timing_reset": (C.c_int, [_vp]),
     "wdpm_timing_get": (C.c_int, [_vp, C.POINTER(C.c_int64), _dp]),
+    "wdpm_timing_get_steady": (C.c_int, [_vp, C.POINTER(C.c_int64), _dp]),
     "wdpm_copy_rows": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, C.c_int32]),
     "wdpm_set_last_error": (None, [C.c_char_p]),
     "wdpm_enable_peer_access": (C.c_int, [_vp, _vp]),
@@ -388,6 +389,12 @@ class Context:
     def timing(self):
         n, ms = C.c_int64(), C.c_double()
         self.lib.check(self.lib.dll.wdpm_timing_get(self._h, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+    def timing_steady(self):
+        """(launches, ms) of the launches between the first and the last of each iterate call"""
+        n, ms = C.c_int64(), C.c_double()
+        self.lib.check(self.lib.dll.wdpm_timing_get_steady(self._h, C.byref(n), C.byref(ms)))
         return n.value, ms.value
 
 

@@ -183,6 +183,8 @@ int wdpm_create(wdpm_ctx **out, const wdpm_params *p) {
   x->signed_zero_safe = false;
   x->launches = 0;
   x->ms = 0.0;
+  x->steady_launches = 0;
+  x->steady_ms = 0.0;
   x->timing = false;
   x->comm = nullptr;
   x->d_dem = x->d_w[0] = x->d_w[1] = x->d_w[2] = nullptr;
@@ -251,6 +253,7 @@ void wdpm_destroy(wdpm_ctx *x) {
   for (int i = 0; i < 2; i++)
     if (x->ev_copy[i]) (void)hipEventDestroy(x->ev_copy[i]);
   for (auto &ep : x->pending) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
+  for (auto &ep : x->pending_steady) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
   for (auto &ep : x->pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
   (void)hipFree(x->d_dem); (void)hipFree(x->d_w[0]); (void)hipFree(x->d_w[1]); (void)hipFree(x->d_w[2]);
   (void)hipFree(x->d_scal); (void)hipFree(x->d_bits); (void)hipFree(x->d_dem32); (void)hipFree(x->d_stat);
@@ -612,6 +615,14 @@ static int fold_timing(wdpm_ctx *x) {
     x->pool.push_back(ep);
   }
   x->pending.clear();
+  for (auto &ep : x->pending_steady) {
+    HIP_TRY(hipEventSynchronize(ep.b));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, ep.a, ep.b));
+    x->steady_ms += ms;
+    x->pool.push_back(ep);
+  }
+  x->pending_steady.clear();
   return 0;
 }
 
@@ -650,7 +661,15 @@ int wdpm_iterate(wdpm_ctx *x, int32_t n_iter) {
     else { HIP_TRY(hipEventCreate(&ep.a)); HIP_TRY(hipEventCreate(&ep.b)); }
     HIP_TRY(hipEventRecord(ep.a, x->stream));
   }
+  EventPair st{nullptr, nullptr};
+  const bool steady = x->timing && n_iter >= 3 && x->kernel == WDPM_KERNEL_FUSED;
+  if (steady) {
+    if (!x->pool.empty()) { st = x->pool.back(); x->pool.pop_back(); }
+    else { HIP_TRY(hipEventCreate(&st.a)); HIP_TRY(hipEventCreate(&st.b)); }
+  }
   for (int it = 0; it < n_iter; it++) {
+    if (steady && it == 1) HIP_TRY(hipEventRecord(st.a, x->stream));
+    if (steady && it == n_iter - 1) HIP_TRY(hipEventRecord(st.b, x->stream));
     if (x->kernel == WDPM_KERNEL_FUSED) {
       if (x->flush_pending && x->signed_zero_safe && ensure_flushed(x)) return 1;   /* no flush-on-load variant of that kernel */
       const int t = free_slot(x);
@@ -700,6 +719,10 @@ int wdpm_iterate(wdpm_ctx *x, int32_t n_iter) {
   if (x->timing) {
     HIP_TRY(hipEventRecord(ep.b, x->stream));
     x->pending.push_back(ep);
+  }
+  if (steady) {
+    x->pending_steady.push_back(st);
+    x->steady_launches += n_iter - 2;
   }
   return 0;
 }
@@ -910,7 +933,17 @@ int wdpm_timing_reset(wdpm_ctx *x) {
   if (fold_timing(x)) return 1;
   x->launches = 0;
   x->ms = 0.0;
+  x->steady_launches = 0;
+  x->steady_ms = 0.0;
   x->timing = true;
+  return 0;
+}
+
+int wdpm_timing_get_steady(wdpm_ctx *x, int64_t *launches, double *ms) {
+  if (bind(x)) return 1;
+  if (fold_timing(x)) return 1;
+  if (launches) *launches = x->steady_launches;
+  if (ms) *ms = x->steady_ms;
   return 0;
 }
 

@@ -66,6 +66,11 @@ struct wdpm_ctx {
   /* stencil timing */
   std::vector<EventPair> pending;
   std::vector<EventPair> pool;
+  /* the same for the launches of a call between its first and its last (those two may be the flush-on-load and the
+   * max-diff variants of the kernel): what rocprofv3 lists as the dominant kernel */
+  std::vector<EventPair> pending_steady;
+  int64_t steady_launches;
+  double steady_ms;
   int64_t launches;
   double ms;
   bool timing;                  /* record the event pairs at all (off until wdpm_timing_reset asks) */
