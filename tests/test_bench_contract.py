@@ -32,7 +32,11 @@ def test_bench_line_has_the_contract_fields():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0
-    assert r["traffic"] is None                         # PMC traffic is only quoted for the configuration it was measured on
+    assert r["traffic"] is None and r["traffic_source"] is None   # PMC traffic is only quoted for the configuration it was measured on
+    # the dominant kernel is the plain instance (launches 2 .. K-1); the all-launch average (flush-on-load first launch,
+    # max-diff last launch included) is reported beside it
+    assert r["kernel_ms_per_iteration"] > 0 and r["kernel_ms_per_iteration_all_launches"] > 0 and "launches 2" in r["kernel"]
+    assert abs(r["moved_frac"] * r["peak"] * r["kernel_ms_per_iteration"] * 1e6 - r["moved_bytes_per_launch"]) < 1e-6 * r["moved_bytes_per_launch"]
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["value"] > 0 and c["unit"] == "cell-updates/s"
     assert "iterations" in c["sample"]
