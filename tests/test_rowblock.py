@@ -313,3 +313,29 @@ def test_hip_drain_outlet_next_to_a_slab_boundary(oracle, hip, where):
     want, mds, stats, _ = group_run(oracle, case, [0], dr, dc)
     got, mds2, stats2, _ = group_run(hip, case, [0, 0], dr, dc)
     assert bits_equal(got, want) and mds2 == mds and stats2 == stats
+
+
+def test_driver_error_paths_report_instead_of_crashing(oracle):
+    """bad arguments to the multi-rank entry points come back as errors with a message (wdpm_last_error)"""
+    import ctypes as C
+    from wdpm_amd.capi import Params, SlabStruct, WdpmError
+    dll = oracle.dll
+    p = Params(module=0, nrows=60, ncols=30, drainrow=0, draincol=0, slab_row0=0, slab_rows=0, device=0, kernel=0,
+               chunk_rows=0, missingvalue=-99999.0)
+    h = C.c_void_p()
+    # more ranks than the raster has room for, a rank outside the world, RCCL without an id, host halos without a transport
+    assert dll.wdpm_rank_create(C.byref(h), C.byref(p), 0, 40, 1, 0, None, None) != 0 and b"too short" in dll.wdpm_last_error()
+    assert dll.wdpm_rank_create(C.byref(h), C.byref(p), 5, 2, 1, 0, None, None) != 0
+    assert dll.wdpm_rank_create(C.byref(h), C.byref(p), 0, 2, 1, 1, None, None) != 0 and b"RCCL" in dll.wdpm_last_error()
+    assert dll.wdpm_rank_create(C.byref(h), C.byref(p), 0, 2, 1, 3, None, None) != 0 and b"transport" in dll.wdpm_last_error()
+    assert dll.wdpm_partition(60, 4, 8, 0, -1, (SlabStruct * 4)()) != 0
+    # a group shrinks instead: first the exchange interval (60 rows serve k = 1 on 4 ranks), then the rank count
+    with Group(oracle, "add", 60, 30, -99999.0, [0, 0, 0, 0], exchange_every=8) as g:
+        assert g.size == 4
+    with Group(oracle, "add", 20, 30, -99999.0, [0] * 8, exchange_every=2) as g:
+        assert 1 <= g.size < 8
+    with Group(oracle, "add", 60, 30, -99999.0, [0, 0], exchange_every=1) as g:
+        with pytest.raises(WdpmError):
+            oracle.check(dll.wdpm_group_set_drain(g._h, 5, 5))      # not a drain group
+        with pytest.raises(WdpmError):
+            oracle.check(dll.wdpm_group_upload_unpadded(g._h, None, None, None))
