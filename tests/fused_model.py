@@ -170,3 +170,94 @@ def fused_iteration(win, dem, miss, H=12):
             run_wave(win, wout, dem, miss, strip, chunk)
     assert not np.isnan(wout).any(), "output cells not covered"
     return wout
+
+
+# ---------------------------------------------------------------------------------------------------
+# The triangle kernel (wdpm_fused.hip: tri_iteration_kernel): nine rows in, the middle three out.
+#   oi = 1 on window rows 0-2, 3-5, 6-8;  oi = 2 on rows 1-3, 4-6;  oi = 3 on rows 2-4.
+# The row blocks of one row alignment are independent (the GPU advances them in lockstep); here they
+# simply run one after the other.
+# ---------------------------------------------------------------------------------------------------
+def run_tri_wave(win, wout, dem, miss, strip, A, out_last):
+    rows, ncp = win.shape
+    c0, oc_lo, oc_hi = strip
+    or_lo, or_hi = (0 if A == 0 else A + 2), min(A + 4, out_last)
+    lane = np.arange(LANES)
+    col = [c0 + 3 * lane + j for j in range(3)]
+    W, D = [], []
+    for i in range(9):
+        r = A + i
+        ws, ds = [], []
+        for j in range(3):
+            ok = (col[j] < ncp) & (r < rows)
+            cc = np.where(col[j] < ncp, col[j], 0)
+            rr = min(r, rows - 1)
+            dd = dem[rr, cc]
+            ws.append(np.where(ok, win[rr, cc], 0.0))
+            ds.append(np.where(ok & (dd > miss), dd, INF))
+        W.append(ws)
+        D.append(ds)
+    for s0 in (0, 3, 6):
+        stage(W, D, s0)      # oi = 1
+    for s0 in (1, 4):
+        stage(W, D, s0)      # oi = 2
+    stage(W, D, 2)           # oi = 3
+    for i in range(5):
+        r = A + i
+        if or_lo <= r <= or_hi:
+            for j in range(3):
+                ok = (col[j] >= oc_lo) & (col[j] <= oc_hi)
+                wout[r, col[j][ok]] = W[i][j][ok]
+
+
+def tri_iteration(win, dem, miss):
+    """One whole iteration with the triangle schedule: chunks of three output rows."""
+    rows, ncp = win.shape
+    wout = np.full_like(win, np.nan)
+    nchunks = max((rows - 1 - 0 - 1 + 2) // 3, 1)
+    for chunk in range(nchunks):
+        for strip in strip_geometry(ncp):
+            run_tri_wave(win, wout, dem, miss, strip, 3 * chunk, rows - 1)
+    assert not np.isnan(wout).any(), "output cells not covered"
+    return wout
+
+
+# ---------------------------------------------------------------------------------------------------
+# Dry tiles (wdpm_kernels.h::TileFlags): per tile (the exact output block of one marching wave) a flag
+# "all +0.0"; a wave whose tile and eight neighbours are flagged in the input raster writes zeros without
+# loading anything.  The model keeps the flags exactly as the kernel does and checks the rule's premise:
+# the skipped wave's output, had it been computed, is all zero.
+# ---------------------------------------------------------------------------------------------------
+def fused_iteration_with_tiles(win, dem, miss, H, zin):
+    """-> (wout, zout, skipped): zin / zout are (nchunks, nstrips) bool arrays or None (unknown)"""
+    assert H >= 6
+    rows, ncp = win.shape
+    chunks, strips = chunk_geometry(rows, H), strip_geometry(ncp)
+    wout = np.full_like(win, np.nan)
+    zout = np.zeros((len(chunks), len(strips)), bool)
+    skipped = 0
+    for ci, chunk in enumerate(chunks):
+        for si, strip in enumerate(strips):
+            dry = zin is not None
+            if dry:
+                for dc in (-1, 0, 1):
+                    for ds in (-1, 0, 1):
+                        cc, ss = ci + dc, si + ds
+                        if 0 <= cc < len(chunks) and 0 <= ss < len(strips):
+                            dry &= bool(zin[cc, ss])
+            A, _, or_lo, or_hi = chunk
+            c0, oc_lo, oc_hi = strip
+            if dry:
+                # what the wave would have computed, to check the rule
+                probe = np.full_like(win, np.nan)
+                run_wave(win, probe, dem, miss, strip, chunk)
+                block = probe[or_lo:or_hi + 1, oc_lo:oc_hi + 1]
+                assert (block.view(np.uint64) == 0).all(), "a tile with a dry neighbourhood produced water"
+                wout[or_lo:or_hi + 1, oc_lo:oc_hi + 1] = 0.0
+                zout[ci, si] = True
+                skipped += 1
+            else:
+                run_wave(win, wout, dem, miss, strip, chunk)
+                zout[ci, si] = (wout[or_lo:or_hi + 1, oc_lo:oc_hi + 1].view(np.uint64) == 0).all()
+    assert not np.isnan(wout).any()
+    return wout, zout, skipped
