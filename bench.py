@@ -122,30 +122,63 @@ def cpu_baseline(n=4096, iters=32):
 
 def self_launch(args):
     """`python bench.py --gpus N` with no launcher: start the N ranks as CHILD processes (never exec: this
-    process has not touched the GPU and will not), relay rank 0's JSON line, return the launcher's status."""
+    process has not touched the GPU and will not), relay rank 0's JSON line, return the launcher's status.
+    If the ranks fail or hang with GPU-direct halos (RCCL communicator set-up is the one step of this path that
+    can block for ever on a node whose fabric or IPC is misconfigured), they are started once more with
+    host-staged halos over gloo; the JSON line says which transport ran (`config.halo`, `config.dist_backend`)."""
+    import signal
     import socket
     import subprocess
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}"]
-    for attempt in range(3):
-        if attempt == 0:       # the launcher picks and holds its own rendezvous port
-            rdzv = ["--standalone", "--local-addr", "127.0.0.1"]
-        else:                  # a port that was free a moment ago
-            with socket.socket() as s:
-                s.bind(("127.0.0.1", 0))
-                rdzv = ["--master-addr", "127.0.0.1", "--master-port", str(s.getsockname()[1])]
-        p = subprocess.run(base + rdzv + [os.path.abspath(__file__), *sys.argv[1:]], stdout=subprocess.PIPE,
-                           stderr=subprocess.PIPE, text=True, env=env)
-        sys.stderr.write(p.stderr)
-        if p.returncode == 0 or "EADDRINUSE" not in p.stderr:
-            break              # only a lost race for the rendezvous port is worth another try
-    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
-    for ln in p.stdout.splitlines():
+    limit = float(os.environ.get("WDPM_BENCH_RANKS_TIMEOUT", "900"))
+
+    def launch(rdzv, env):
+        """-> (return code or None on timeout, stdout, stderr); the children get their own process group so that a
+        hung run can be ended as a whole (by that exact group id, nothing else)"""
+        p = subprocess.Popen(base + rdzv + [os.path.abspath(__file__), *sys.argv[1:]], stdout=subprocess.PIPE,
+                             stderr=subprocess.PIPE, text=True, env=env, start_new_session=True)
+        try:
+            out, err = p.communicate(timeout=limit)
+            return p.returncode, out, err
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(p.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+            out, err = p.communicate()
+            return None, out, err
+
+    def run(env):
+        for attempt in range(3):
+            if attempt == 0:       # the launcher picks and holds its own rendezvous port
+                rdzv = ["--standalone", "--local-addr", "127.0.0.1"]
+            else:                  # a port that was free a moment ago
+                with socket.socket() as s:
+                    s.bind(("127.0.0.1", 0))
+                    rdzv = ["--master-addr", "127.0.0.1", "--master-port", str(s.getsockname()[1])]
+            rc, out, err = launch(rdzv, env)
+            sys.stderr.write(err)
+            if rc == 0 or rc is None or "EADDRINUSE" not in err:
+                break              # only a lost race for the rendezvous port is worth another try
+        return rc, out
+
+    rc, out = run(env)
+    lines = [ln for ln in out.splitlines() if ln.startswith('{"metric"')]
+    gpu_direct = env.get("WDPM_HALO", "rccl") == "rccl" and env.get("WDPM_DIST_BACKEND", "nccl") == "nccl"
+    if (rc != 0 or not lines) and gpu_direct:
+        print(f"bench.py: the ranks {'did not finish within %.0f s' % limit if rc is None else 'ended with status %d' % rc} "
+              f"on RCCL halos; starting them again with host-staged halos over gloo", file=sys.stderr, flush=True)
+        rc, out = run(dict(env, WDPM_HALO="host", WDPM_DIST_BACKEND="gloo"))
+        lines = [ln for ln in out.splitlines() if ln.startswith('{"metric"')]
+    for ln in out.splitlines():
         if not ln.startswith('{"metric"'):
             print(ln, file=sys.stderr)
     if lines:
         print(lines[-1], flush=True)
-    return p.returncode if p.returncode != 0 or lines else 1
+    if rc is None:
+        return 124
+    return rc if rc != 0 or lines else 1
 
 
 def main():
