@@ -343,6 +343,15 @@ def test_degenerate_shapes(hip, oracle, R, C):
     _compare_with_oracle(hip, oracle, "drain", R, C, seed=R * 7 + C + 1, iters=(4,), kernel=wdpm_amd.KERNEL_FUSED)
 
 
+@pytest.mark.parametrize("R,C", [(2, 50000), (50000, 2), (7, 30000), (30000, 7), (1, 100000), (100000, 1)])
+def test_extreme_aspect_ratios(hip, oracle, R, C):
+    """hundreds of strips one chunk high, and one strip thousands of chunks high: the launch geometry at its ends
+    (both the marching and, where it is chosen, the triangle kernel), against the oracle"""
+    _compare_with_oracle(hip, oracle, "add", R, C, seed=R + 3 * C, iters=(1, 3), kernel=wdpm_amd.KERNEL_FUSED)
+    _compare_with_oracle(hip, oracle, "drain", R, C, seed=R + 3 * C + 1, iters=(3,), kernel=wdpm_amd.KERNEL_FUSED)
+    _compare_with_oracle(hip, oracle, "add", R, C, seed=R + 3 * C + 2, iters=(2, 2), kernel=wdpm_amd.KERNEL_FUSED, thres=5e-6)
+
+
 def test_one_block_of_1000_iterations_at_8192(hip):
     """a whole reference block (1000 iterations) at 8192^2: the kernel streaming the DEM as verified 32-bit
     codes and the one reading the fp64 DEM end on identical bits and identical max diff; volume conserved;
