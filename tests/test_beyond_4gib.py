@@ -1,0 +1,57 @@
+"""Rasters of more than 4 GiB each (byte offsets past 2^32, 5.8 * 10^8 cells): three copies of one 8001 x 24000 basin stacked with
+NODATA rows between them.  The copies cannot exchange water, start on the same row colour (8001 = 0 mod 3), and so must
+come out identical bit for bit - to each other and to the basin run on its own in a raster of 1.5 GiB.  A size-independent
+property, no oracle run of half a billion cells needed; every kernel of the block loop addresses past 4 GiB here."""
+import numpy as np
+import pytest
+
+import wdpm_amd
+from helpers import n_bit_diff
+
+pytestmark = pytest.mark.gpu
+
+@pytest.mark.parametrize("rows,cols,copies", [(8000, 24000, 3), (8798, 44000, 5)])
+def test_stacked_basins_past_4gib(hip, rows, cols, copies):
+    """(8000, 24000, 3): 4.6 GB per raster.  (8798, 44000, 5): 43994 x 44000, 1.936e9 padded cells - just under the 2e9 cells one
+    context takes (wdpm_create), 15.5 GB per raster, 70 GB of HBM"""
+    psutil = pytest.importorskip("psutil")
+    need = (48 if copies == 3 else 128) * 2 ** 30
+    if psutil.virtual_memory().available < need:
+        pytest.skip("needs %d GiB of free host memory" % (need >> 30))
+    miss, thres = -99999.0, 5e-6
+    rng = np.random.default_rng(cols)
+    y = np.arange(rows)[:, None]
+    x = np.arange(cols)[None, :]
+    dem = np.round(500.0 + 3.0 * np.sin(x / 37.0) * np.cos(y / 53.0) - 1e-4 * x + 0.05 * rng.random((rows, cols)), 4)
+    dem[rng.random((rows, cols)) < 0.01] = miss
+    water = np.where(dem > miss, 0.1, 0.0)
+    water[rng.random((rows, cols)) < 0.3] = 0.0
+
+    def padded(ncopies):
+        R = ncopies * (rows + 1) - 1
+        bd = np.full((R + 2, cols + 2), miss)
+        bw = np.zeros((R + 2, cols + 2))
+        for k in range(ncopies):
+            r0 = 1 + k * (rows + 1)
+            bd[r0:r0 + rows, 1:-1] = dem
+            bw[r0:r0 + rows, 1:-1] = water
+        return R, bd, bw
+
+    def run(ncopies):
+        R, bd, bw = padded(ncopies)
+        with hip.context(module="add", nrows=R, ncols=cols, missingvalue=miss, kernel=wdpm_amd.KERNEL_FUSED) as c:
+            c.upload(bd, bw)
+            del bd, bw
+            md = [c.run_block(3, thres), c.run_block(2, thres)]
+            dem32 = c.get_option(wdpm_amd.OPT_DEM32)
+            return md, c.download_water(), dem32
+
+    md1, w1, _ = run(1)
+    md3, w3, dem32 = run(copies)
+    assert w3.nbytes > 2 ** 32 and dem32 == 1
+    assert md1 == md3                                     # the maximum over identical basins
+    for k in range(copies):
+        r0 = 1 + k * (rows + 1)
+        assert n_bit_diff(w3[r0:r0 + rows], w1[1:1 + rows]) == 0, k
+    for k in range(1, copies):
+        assert not w3[k * (rows + 1)].any()                                # the separator rows stay dry
