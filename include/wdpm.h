@@ -63,7 +63,9 @@ typedef struct wdpm_params {
 
 /* -- lifetime ------------------------------------------------------------------------------
  * replaces OpenCL context/program/queue/kernel creation (WDPMCL.c:598-638) and the per-block
- * clCreateBuffer/clReleaseMemObject churn (WDPMCL.c:1138-1141,1223-1227): buffers persist. */
+ * clCreateBuffer/clReleaseMemObject churn (WDPMCL.c:1138-1141,1223-1227): buffers persist.
+ * One context takes at most 2e9 padded cells ((nrows + 2) * (ncols + 2)); a larger raster goes into several row blocks
+ * (wdpm_group_create may name one device more than once). */
 int  wdpm_create(wdpm_ctx **out, const wdpm_params *p);
 void wdpm_destroy(wdpm_ctx *ctx);                      /* WDPMCL.c:1475-1483 */
 const char *wdpm_last_error(void);                     /* replaces exitOnFail(), WDPMCL.c:225-232; per host thread */

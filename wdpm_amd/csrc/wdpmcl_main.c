@@ -458,6 +458,21 @@ static int device_list(int32_t *dev, int max) {
   return n;
 }
 
+/* One context addresses at most 2e9 padded cells (wdpm_create: 32-bit cell indices inside a row block).  The reference's
+ * serial path has no such limit, so a larger raster is cut into more row blocks on the SAME device(s): each device of the
+ * list is named `per` times in a row and the usual row-block driver does the rest (halos between slabs of one device are
+ * device-to-device copies).  WDPM_MAX_SLAB_CELLS overrides the threshold (tests). */
+static int split_for_size(int32_t *dev, int n, const int max, const double padded_cells) {
+  const double lim = getenv("WDPM_MAX_SLAB_CELLS") ? atof(getenv("WDPM_MAX_SLAB_CELLS")) : 1.9e9;
+  if (!(lim > 0) || padded_cells <= lim * n) return n;
+  int per = (int)((padded_cells + lim * n - 1) / (lim * n));
+  if (n * per > max) per = max / n;
+  if (per <= 1) return n;
+  for (int i = n - 1; i >= 0; i--)
+    for (int k = per - 1; k >= 0; k--) dev[i * per + k] = dev[i];
+  return n * per;
+}
+
 /* ---- scratch (checkpoint) writer -------------------------------------------------------------
  * The reference rewrites the scratch raster after every block that does not end the run
  * (WDPMCL.c:1290-1372) and stalls the loop while fprintf runs.  Here the loop only pays for the
@@ -693,7 +708,7 @@ int main(int argc, char **argv) {
   p.drainrow = cfg.module == WDPM_DRAIN ? (host_drain_search ? st.drainrow : -1) : 0;
   p.draincol = cfg.module == WDPM_DRAIN ? (host_drain_search ? st.draincol : -1) : 0;
   int32_t devices[64];
-  const int ndev_asked = device_list(devices, 64);
+  const int ndev_asked = split_for_size(devices, device_list(devices, 64), 64, ((double)p.nrows + 2) * ((double)p.ncols + 2));
   const int every = getenv("WDPM_EXCHANGE_EVERY") ? atoi(getenv("WDPM_EXCHANGE_EVERY")) : 4;
   wdpm_setup su;
   memset(&su, 0, sizeof su);
