@@ -149,7 +149,7 @@ int wdpm_create(wdpm_ctx **out, const wdpm_params *p) {
   const int rows = p->slab_rows > 0 ? p->slab_rows : p->nrows + 2;
   if (p->slab_row0 + rows > p->nrows + 2) return fail("wdpm_create: slab exceeds raster");
   if (rows < 3) return fail("wdpm_create: a slab needs at least 3 rows");
-  if ((double)(p->nrows + 2) * (double)(p->ncols + 2) > 2.0e9) return fail("wdpm_create: raster too large for 32-bit cell indices per row block");
+  if ((double)rows * (double)(p->ncols + 2) > 2.0e9) return fail("wdpm_create: raster too large: a row block takes at most 2e9 cells (%d rows x %d here; use more row blocks)", rows, p->ncols + 2);
   int ndev = 0;
   HIP_TRY(hipGetDeviceCount(&ndev));
   if (ndev < 1) return fail("wdpm_create: no HIP device (this library has no CPU fallback)");
