@@ -59,40 +59,45 @@ def test_stacked_basins_past_4gib(hip, rows, cols, copies):
 
 def test_more_cells_than_one_context_takes(hip):
     """46 007 x 46 000 = 2.12e9 padded cells: refused by wdpm_create, run as two row blocks on the one device (what WDPMCL does
-    by itself for such a raster), six stacked copies of a basin that must all equal the basin run alone"""
+    by itself for such a raster) through the calls WDPMCL makes - set-up from the un-padded file rasters, counts, outlet search,
+    block loop, volume sum, masked un-padded download.  Six stacked copies of a basin that must all equal the basin run alone."""
     from wdpm_amd.rowblock import Group
     psutil = pytest.importorskip("psutil")
-    if psutil.virtual_memory().available < 160 * 2 ** 30:
-        pytest.skip("needs 160 GiB of free host memory")
+    if psutil.virtual_memory().available < 200 * 2 ** 30:
+        pytest.skip("needs 200 GiB of free host memory")
     rows, cols, copies, miss, thres = 7667, 46000, 6, -99999.0, 5e-6
     rng = np.random.default_rng(46000)
     y = np.arange(rows)[:, None]
     x = np.arange(cols)[None, :]
     dem = np.round(500.0 + 2.0 * np.sin(x / 41.0) * np.cos(y / 29.0) - 1e-4 * x + 0.05 * rng.random((rows, cols)), 4)
-    water = np.where(rng.random((rows, cols)) < 0.6, 0.1, 0.0)
+    dem[rng.random((rows, cols)) < 0.01] = miss
+    wet = (rng.random((rows, cols)) < 0.6) & (dem > miss)
     R = copies * (rows + 1) - 1
     with pytest.raises(wdpm_amd.capi.WdpmError, match="too large"):
         hip.context(module="add", nrows=R, ncols=cols, missingvalue=miss)
-    bd = np.full((R + 2, cols + 2), miss)
-    bw = np.zeros((R + 2, cols + 2))
+    fdem = np.full((R, cols), miss)                       # the file rasters: un-padded
+    fwat = np.zeros((R, cols))
     for k in range(copies):
-        r0 = 1 + k * (rows + 1)
-        bd[r0:r0 + rows, 1:-1] = dem
-        bw[r0:r0 + rows, 1:-1] = water
-    assert bd.size > 2e9
-    grp = Group(hip, "add", R, cols, miss, [0, 0], exchange_every=2)
-    try:
-        grp.upload(bd, bw)
-        del bd, bw
+        r0 = k * (rows + 1)
+        fdem[r0:r0 + rows] = dem
+        fwat[r0:r0 + rows] = np.where(wet, 0.05, 0.0)
+    assert (R + 2) * (cols + 2) > 2e9
+    with Group(hip, "add", R, cols, miss, [0, 0], exchange_every=2) as grp:
+        grp.upload_unpadded(fdem, fwat, op=1, add=0.05, rof=0.0)          # WDPMCL.c:727-740: wet cells + 0.05, dry cells stay dry
+        del fwat
+        nvalid, nwet, wmax = grp.count_stats()
+        assert (nvalid, nwet, wmax) == (copies * int((dem > miss).sum()), copies * int(wet.sum()), 0.1)
+        k = int(np.argmin(np.where(dem > 0, dem, np.inf)))                # :1005-1017 the first row-major minimum
+        assert grp.find_drain() == (float(dem.flat[k]), k // cols + 1, k % cols + 1)
         md = [grp.run_block(3, thres), grp.run_block(2, thres)]
-        w = grp.download_water()
-    finally:
-        grp.close()
+        _, vol = grp.drain_stats()
+        w = grp.download_unpadded(True)
     with hip.context(module="add", nrows=rows, ncols=cols, missingvalue=miss, kernel=wdpm_amd.KERNEL_FUSED) as c:
-        c.upload(np.pad(dem, 1, constant_values=miss), np.pad(water, 1))
+        c.upload(np.pad(dem, 1, constant_values=miss), np.pad(np.where(wet, 0.1, 0.0), 1))
         md1 = [c.run_block(3, thres), c.run_block(2, thres)]
-        w1 = c.download_water()
+        w1 = np.where(dem > miss, c.download_water()[1:-1, 1:-1], miss)
     assert md == md1
     for k in range(copies):
-        r0 = 1 + k * (rows + 1)
-        assert n_bit_diff(w[r0:r0 + rows], w1[1:1 + rows]) == 0, k
+        r0 = k * (rows + 1)
+        assert n_bit_diff(w[r0:r0 + rows], w1) == 0, k
+    assert vol == float(np.add.accumulate(w[fdem > miss])[-1])            # the sequential row-major sum, :1262-1268
