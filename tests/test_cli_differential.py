@@ -1,0 +1,35 @@
+"""Differential test of the WDPMCL command line against the UNMODIFIED reference executable on random small jobs with
+oddly formatted input files (tests/cli_fuzz.py): same exit code, same report (minus wall clock), same bytes in the output
+and scratch rasters.  CPU: the product's host code on the oracle back-end; GPU box: the shipped binary on the HIP path.
+The reference executable is built where /root/reference exists (oracle/Makefile `ref`) and travels prebuilt."""
+import os
+
+import pytest
+
+from cli_fuzz import first_difference, one
+from conftest import ROOT
+
+REF_CLI = os.path.join(ROOT, "oracle", "_ref", "WDPMCL_ref")
+ORACLE_CLI = os.path.join(ROOT, "oracle", "_build", "WDPMCL_oracle")
+HIP_CLI = os.path.join(ROOT, "wdpm_amd", "bin", "WDPMCL")
+
+needs_ref = pytest.mark.skipif(not os.path.exists(REF_CLI), reason="oracle/_ref/WDPMCL_ref not built (needs /root/reference)")
+
+
+def differential(exe, seeds, tmp_path):
+    for seed in seeds:
+        ok, ref, new, style, info = one(seed, str(tmp_path), REF_CLI, exe)
+        assert ok, (f"seed {seed} {info} {style}: exit codes {ref[0]} / {new[0]}, files {ref[2]} / {new[2]}, "
+                    f"{first_difference(ref[1], new[1])}, args {ref[3]}")
+        assert ref[0] == 0 and ref[2]["out.asc"] is not None          # the jobs are valid ones: the reference ran them
+
+
+@needs_ref
+def test_cli_equals_the_reference_executable_on_random_jobs(oracle, tmp_path):
+    differential(ORACLE_CLI, range(0, 120), tmp_path)
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_hip_cli_equals_the_reference_executable_on_random_jobs(tmp_path):
+    differential(HIP_CLI, range(1000, 1060), tmp_path)
