@@ -314,6 +314,52 @@ def test_subnormal_depths_are_not_flushed(hip, oracle):
         assert ((wg > 0) & (wg < 2.2e-308)).any()           # subnormals survived
 
 
+@pytest.mark.parametrize("module", ["add", "drain"])
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_adversarial_operands(hip, oracle, module, seed):
+    """Elevations and depths drawn from pools built to hit the corners of the neighbour step on the GPU's own instructions
+    (v_ldexp / v_max / v_min without canonicalisation, the -inf gate, the ldexp(ht, 2200) sign trick of the drain step):
+    exact ties of water surfaces, depths from one subnormal ulp to 1e300 next to elevations from 1e-4 to 1e15, neighbours
+    one ulp apart, water that exactly fills the step to its neighbour.  Several iterations, bit for bit against the oracle."""
+    rng = np.random.default_rng(100 + seed)
+    R, C, miss = 120, 400, -99999.0
+    dpool = np.array([1e-4, 0.5, 1.0, 499.9999, 500.0, np.nextafter(500.0, 501), 500.0001, 500.1, 512.0, 1e6, 1e15])
+    if seed == 4:       # decimal elevations only: the DEM goes through the 32-bit codes (forced below)
+        dpool = np.array([1e-4, 0.5, 1.0, 499.9999, 500.0, 500.0001, 500.1, 512.0, 99999.9999])
+    wpool = np.array([0.0, 0.0, 0.0, 5e-324, 1e-310, 2.3e-308, 1e-300, 1e-16, 1.1368683772161603e-13, 1e-4, 1e-4, 0.1, 0.1,
+                      np.nextafter(0.1, 1), 0.7999999999999, 0.8, 1.0, 8.0, 1e6, 1e300])
+    dem = dpool[rng.integers(0, len(dpool), (R, C))]
+    water = wpool[rng.integers(0, len(wpool), (R, C))]
+    # runs of equal elevations / equal surfaces along rows so that ties and one-ulp differences meet as neighbours
+    same = rng.random((R, C)) < 0.4
+    for arr in (dem, water):
+        arr[:, 1:] = np.where(same[:, 1:], arr[:, :-1], arr[:, 1:])
+    fill = rng.random((R, C)) < 0.1                           # depth that brings the surface exactly to the left neighbour's
+    water[:, 1:] = np.where(fill[:, 1:] & (dem[:, :-1] > dem[:, 1:]), dem[:, :-1] - dem[:, 1:], water[:, 1:])
+    dem[rng.random((R, C)) < 0.05] = miss
+    water[dem <= miss] = 0.0
+    bd, bw = pad(dem, water, miss)
+    kw = dict(module=module, nrows=R, ncols=C, missingvalue=miss)
+    if module == "drain":
+        dr, dc = find_drain(bd)
+        kw.update(drainrow=dr, draincol=dc)
+    for kernel in (wdpm_amd.KERNEL_FUSED, wdpm_amd.KERNEL_PASS):
+        with hip.context(kernel=kernel, **kw) as g, oracle.context(**kw) as o:
+            for c in (g, o):
+                c.upload(bd, bw)
+            if seed == 4 and module == "add":
+                g.set_option(wdpm_amd.OPT_DEM32, 2)
+                assert g.get_option(wdpm_amd.OPT_DEM32) == 1
+            for n in (1, 2, 9):
+                g.iterate(n)
+                o.iterate(n)
+                wg, wo = g.download_water(), o.download_water()
+                assert n_bit_diff(wg, wo) == 0, (kernel, n)
+                assert g.totaldrain == o.totaldrain
+            assert g.run_block(4, 1e-5) == o.run_block(4, 1e-5)
+            assert n_bit_diff(g.download_water(), o.download_water()) == 0
+
+
 def test_negative_elevations_and_other_nodata(hip, oracle):
     """terrain below datum and a different NODATA code"""
     rng = np.random.default_rng(42)
