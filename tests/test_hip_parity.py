@@ -343,8 +343,9 @@ def test_adversarial_operands(hip, oracle, module, seed):
     if module == "drain":
         dr, dc = find_drain(bd)
         kw.update(drainrow=dr, draincol=dc)
-    for kernel in (wdpm_amd.KERNEL_FUSED, wdpm_amd.KERNEL_PASS):
-        with hip.context(kernel=kernel, **kw) as g, oracle.context(**kw) as o:
+    # the triangle kernel (a raster this small), the marching kernel (a chunk height is asked for), the per-pass kernel
+    for kernel, chunk in ((wdpm_amd.KERNEL_FUSED, 0), (wdpm_amd.KERNEL_FUSED, 12), (wdpm_amd.KERNEL_PASS, 0)):
+        with hip.context(kernel=kernel, chunk_rows=chunk, **kw) as g, oracle.context(**kw) as o:
             for c in (g, o):
                 c.upload(bd, bw)
             if seed == 4 and module == "add":
@@ -354,7 +355,7 @@ def test_adversarial_operands(hip, oracle, module, seed):
                 g.iterate(n)
                 o.iterate(n)
                 wg, wo = g.download_water(), o.download_water()
-                assert n_bit_diff(wg, wo) == 0, (kernel, n)
+                assert n_bit_diff(wg, wo) == 0, (kernel, chunk, n)
                 assert g.totaldrain == o.totaldrain
             assert g.run_block(4, 1e-5) == o.run_block(4, 1e-5)
             assert n_bit_diff(g.download_water(), o.download_water()) == 0
