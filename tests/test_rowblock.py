@@ -339,3 +339,49 @@ def test_driver_error_paths_report_instead_of_crashing(oracle):
             oracle.check(dll.wdpm_group_set_drain(g._h, 5, 5))      # not a drain group
         with pytest.raises(WdpmError):
             oracle.check(dll.wdpm_group_upload_unpadded(g._h, None, None, None))
+
+
+def _random_group_jobs(lib, ref_lib, seeds):
+    """random rasters (3 .. 160 rows), 2 .. 7 slabs on one device, exchange every 1 .. 6 iterations, any module, the drain
+    outlet anywhere, blocks of 1 .. 9 iterations with and without a flush threshold: the group's max change, rasters,
+    totaldrain and drain statistics against ONE context of `ref_lib` (the oracle)"""
+    import random
+    for seed in seeds:
+        rng = random.Random(seed)
+        R, C = rng.randint(3, 160), rng.randint(1, 60)
+        n, k = rng.randint(2, 7), rng.randint(1, 6)
+        module = rng.choice(["add", "drain", "subtract"])
+        dem, water, miss = random_case(seed, R, C, missing_frac=rng.choice([0, 0.05, 0.3]))
+        bd, bw = pad(dem, water, miss)
+        kw = {}
+        if module == "drain":
+            dr, dc = find_drain(bd)
+            valid = np.argwhere(bd > miss)
+            if rng.random() < 0.5 and len(valid):
+                dr, dc = map(int, valid[rng.randrange(len(valid))])
+            kw = dict(drainrow=dr, draincol=dc)
+        iters = [rng.randint(1, 9) for _ in range(3)]
+        thres = rng.choice([0.0, 1e-5])
+        with ref_lib.context(module=module, nrows=R, ncols=C, missingvalue=miss, **kw) as c:
+            c.upload(bd, bw)
+            if module == "drain":
+                c.totaldrain = max(float(bw[dr, dc]), 0.0)
+            want = ([c.run_block(i, thres) for i in iters], c.totaldrain, c.drain_stats() if module == "drain" else None)
+            w1 = c.download_water()
+        with Group(lib, module, R, C, miss, [0] * n, exchange_every=k, **kw) as g:
+            g.upload(bd, bw)
+            if module == "drain":
+                g.set_totaldrain(max(float(bw[dr, dc]), 0.0))
+            got = ([g.run_block(i, thres) for i in iters], g.totaldrain() if module == "drain" else want[1],
+                   g.drain_stats() if module == "drain" else None)
+            assert got == want, (seed, R, C, n, k, module, kw, g.size)
+            assert n_bit_diff(g.download_water(), w1) == 0, (seed, R, C, n, k, module, kw, g.size)
+
+
+def test_random_group_jobs_equal_one_context(oracle):
+    _random_group_jobs(oracle, oracle, range(0, 150))
+
+
+@pytest.mark.gpu
+def test_hip_random_group_jobs_equal_the_oracle(oracle, hip):
+    _random_group_jobs(hip, oracle, range(2000, 2080))
