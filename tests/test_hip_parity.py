@@ -497,6 +497,36 @@ def test_volume_sum_is_the_sequential_sum(hip, name):
         assert np.float64(chained).view(np.uint64) == np.float64(want).view(np.uint64) or np.isnan(want)
 
 
+def _play(c, script, R, module):
+    out = []
+    for op in script:
+        if op[0] == "begin":
+            c.begin_block(op[1])
+        elif op[0] == "expect":
+            c.expect_max_diff(op[1], op[2])
+        elif op[0] == "maxdiff":
+            out.append(c.max_diff(*op[1:]))
+        elif op[0] == "download":
+            out.append(c.download_water())
+        elif op[0] == "upload_water":
+            c.upload_water(op[1])
+        elif op[0] == "upload_rows":
+            c.upload_rows(op[1], op[2])
+        elif op[0] == "iterate":
+            c.iterate(op[1])
+        elif op[0] == "iterate_overlapped":
+            c.iterate_overlapped(op[1], op[2], op[3])
+        elif op[0] == "pass":
+            c.single_pass(op[1], op[2])
+        elif op[0] == "outlet":
+            c.drain_outlet()
+        elif op[0] == "volume":
+            out.append(c.volume_partial(0, R + 2, 0.0))
+    if module == "drain":
+        out.append(c.totaldrain)
+    return out
+
+
 @pytest.mark.parametrize("module", ["add", "drain"])
 @pytest.mark.parametrize("kernel", [wdpm_amd.KERNEL_FUSED, wdpm_amd.KERNEL_PASS])
 def test_lazy_flush_and_snapshot_rotation(hip, oracle, module, kernel):
@@ -540,34 +570,7 @@ def test_lazy_flush_and_snapshot_rotation(hip, oracle, module, kernel):
         [("it", 3), ("expect", 0, R + 2), ("it", 2), ("maxdiff",), ("begin", t2), ("expect", 0, R + 2), ("it", 2), ("maxdiff",)],
     ]
 
-    def play(c, script):
-        out = []
-        for op in script:
-            if op[0] == "begin":
-                c.begin_block(op[1])
-            elif op[0] == "expect":
-                c.expect_max_diff(op[1], op[2])
-            elif op[0] == "maxdiff":
-                out.append(c.max_diff(*op[1:]))
-            elif op[0] == "download":
-                out.append(c.download_water())
-            elif op[0] == "upload_water":
-                c.upload_water(op[1])
-            elif op[0] == "upload_rows":
-                c.upload_rows(op[1], op[2])
-            elif op[0] == "iterate":
-                c.iterate(op[1])
-            elif op[0] == "iterate_overlapped":
-                c.iterate_overlapped(op[1], op[2], op[3])
-            elif op[0] == "pass":
-                c.single_pass(op[1], op[2])
-            elif op[0] == "outlet":
-                c.drain_outlet()
-            elif op[0] == "volume":
-                out.append(c.volume_partial(0, R + 2, 0.0))
-        if module == "drain":
-            out.append(c.totaldrain)
-        return out
+    play = lambda c, script: _play(c, script, R, module)   # noqa: E731
 
     for script in scripts:
         with hip.context(kernel=kernel, **kw) as g, oracle.context(**kw) as o:
@@ -581,6 +584,77 @@ def test_lazy_flush_and_snapshot_rotation(hip, oracle, module, kernel):
                 assert n_bit_diff(a, b) == 0, [op[0] for op in script]
             else:
                 assert a == b, ([op[0] for op in script], a, b)
+
+
+@pytest.mark.parametrize("module", ["add", "drain"])
+def test_random_call_sequences(hip, oracle, module):
+    """The library's lazy state (pending flush, owed drain(), raster rotation, tile flags, the folded max-change) driven by
+    RANDOM sequences of ABI calls on rasters of random shape, chunk height and kernel: after every observing call the HIP
+    context must show exactly what the oracle's eager implementation shows."""
+    import random
+    lo, hi = (int(v) for v in os.environ.get("WDPM_FUZZ_SEEDS", "0:60").split(":"))     # a longer hunt: WDPM_FUZZ_SEEDS=60:2000
+    for seed in range(lo, hi):
+        rng = random.Random(seed * 3 + (module == "drain"))
+        R, C = rng.randint(4, 90), rng.randint(3, 420)
+        dem, water, miss = random_case(500 + seed, R, C, missing_frac=rng.choice([0.0, 0.05, 0.4]), dry_frac=rng.choice([0.1, 0.6, 0.95]))
+        water = np.where(water < 0.05, water * 1e-3, water)
+        bd, bw = pad(dem, water, miss)
+        nrng = np.random.default_rng(seed)
+        kw = dict(module=module, nrows=R, ncols=C, missingvalue=miss)
+        if module == "drain":
+            dr, dc = find_drain(bd)
+            kw.update(drainrow=dr, draincol=dc)
+        script = []
+        for _ in range(rng.randint(6, 14)):
+            op = rng.choice(["begin", "begin", "it", "it", "it", "iterate_overlapped", "maxdiff", "maxdiff", "expect", "download",
+                             "upload_rows", "upload_water", "pass", "outlet", "volume"])
+            if op == "begin":
+                script.append(("begin", rng.choice([0.0, 1e-3, 4e-3])))
+            elif op == "it":
+                script.append(("iterate", rng.randint(1, 5)))
+            elif op == "iterate_overlapped":
+                if R + 2 >= 40:
+                    top, bot = rng.randint(0, 15), rng.randint(0, 15)
+                    script.append(("iterate_overlapped", rng.randint(1, 3), top, bot))
+            elif op == "maxdiff":
+                lo = rng.randint(0, R); hi = rng.randint(lo + 1, R + 2)
+                script.append(("maxdiff",) if rng.random() < 0.6 else ("maxdiff", lo, hi))
+            elif op == "expect":
+                lo = rng.randint(0, R); hi = rng.randint(lo + 1, R + 2)
+                script.append(("expect", 0, R + 2) if rng.random() < 0.6 else ("expect", lo, hi))
+            elif op == "upload_rows":
+                n = rng.randint(1, min(5, R + 2)); r0 = rng.randint(0, R + 2 - n)
+                rows = np.where(bd[r0:r0 + n] > miss, 0.3 * nrng.random((n, C + 2)), 0.0)
+                script.append(("upload_rows", r0, rows))
+            elif op == "upload_water":
+                script.append(("upload_water", np.where(bd > miss, 0.2 * nrng.random(bd.shape), 0.0)))
+            elif op == "pass":
+                script.append(("pass", rng.randint(1, 3), rng.randint(1, 3)))
+            elif op == "outlet":
+                if module == "drain":
+                    script.append(("outlet",))
+            else:
+                script.append((op,))
+        script.append(("maxdiff",))
+        script.append(("download",))
+        kernel = rng.choice([wdpm_amd.KERNEL_FUSED, wdpm_amd.KERNEL_FUSED, wdpm_amd.KERNEL_PASS])
+        chunk = rng.choice([0, 0, 6, 12, 30])
+        with hip.context(kernel=kernel, chunk_rows=chunk, **kw) as g, oracle.context(**kw) as o:
+            for c in (g, o):
+                c.upload(bd, bw)
+                c.totaldrain = 0.25
+            if rng.random() < 0.3:
+                g.set_option(wdpm_amd.capi.OPT_TILES, 0)
+            if module == "add" and rng.random() < 0.4:
+                g.set_option(wdpm_amd.OPT_DEM32, 2)
+            got, want = _play(g, script, R, module), _play(o, script, R, module)
+        names = [op[0] for op in script]
+        assert len(got) == len(want)
+        for a, b in zip(got, want):
+            if isinstance(a, np.ndarray):
+                assert n_bit_diff(a, b) == 0, (seed, R, C, kernel, chunk, names)
+            else:
+                assert a == b, (seed, R, C, kernel, chunk, names, a, b)
 
 
 @pytest.mark.parametrize("chunk", [0, 6])
