@@ -22,23 +22,25 @@ def host_setup(dem, water, miss, op, add=0.0, rof=0.0, sub=0.0):
     return pad(dem, w, miss)
 
 
-def check(lib, devices, module, op, kw, with_water):
-    R, C = 97, 230
-    dem, water, miss = random_case(303, R, C, missing_frac=0.2, dry_frac=0.4)
+def check(lib, devices, module, op, kw, with_water, R=97, C=230, seed=303, missing_frac=0.2, exchange_every=2):
+    dem, water, miss = random_case(seed, R, C, missing_frac=missing_frac, dry_frac=0.4)
     water[dem <= miss] = miss                     # as in an output raster of a previous run: NODATA cells hold the NODATA value
     if not with_water:
         water = None
     bd, bw = host_setup(dem, np.zeros_like(dem) if water is None else water, miss, op, **kw)
     dr, dc = find_drain(bd)
     gkw = dict(drainrow=-1, draincol=-1) if module == "drain" else {}
-    with Group(lib, module, R, C, miss, devices, exchange_every=2, **gkw) as g:
+    with Group(lib, module, R, C, miss, devices, exchange_every=exchange_every, **gkw) as g:
         g.upload_unpadded(dem, water, op=op, **kw)
         assert bits_equal(g.download_water(), bw)                                 # padded rasters as the host would build them
         valid, wet, mx = g.count_stats()
         v = bd > miss
         assert valid == int(v.sum()) and wet == int((v & (bw > 0.001)).sum())
         assert mx == float(np.where(v, bw, miss).max())
-        assert g.find_drain() == (float(bd[dr, dc]), dr, dc)
+        if (bd > 0).any():
+            assert g.find_drain() == (float(bd[dr, dc]), dr, dc)
+        else:                                         # no cell above 0: the reference leaves drainrow = draincol = 0 (:1006-1017)
+            assert g.find_drain()[1:] == (0, 0) and (dr, dc) == (0, 0)
         assert g.get_cell(dr, dc) == (float(bw[dr, dc]), float(bd[dr, dc]))
         if module == "drain":
             rc = g.set_drain(dr, dc)
@@ -51,7 +53,8 @@ def check(lib, devices, module, op, kw, with_water):
             want = np.where(dem > miss, w, miss) if mask else w
             assert bits_equal(g.download_unpadded(mask), want)
         _, vol = g.drain_stats()
-        assert vol == float(np.add.accumulate(g.download_water()[bd > miss])[-1])
+        vals = g.download_water()[bd > miss]
+        assert vol == (float(np.add.accumulate(vals)[-1]) if len(vals) else 0.0)
 
 
 @pytest.mark.parametrize("module,op,kw", CASES)
@@ -79,3 +82,23 @@ def test_outlet_next_to_a_boundary_asks_for_a_new_partition(oracle):
         g.upload_unpadded(dem, None)
         assert g.set_drain(b + 1, 7) == 2 and g.set_drain(b - 2, 7) == 2
         assert g.set_drain(b + 3, 7) == 0 and g.set_drain(b - 4, 7) == 0
+
+
+def random_shapes(lib, seeds):
+    """the same checks on random shapes (1 x 1 ... 150 x 300), 1 - 6 slabs, any module, with and without a water file"""
+    import random
+    for seed in seeds:
+        rng = random.Random(seed)
+        module, op, kw = CASES[rng.randrange(3)]
+        R, C = rng.choice([(1, 1), (2, 5), (rng.randint(3, 150), rng.randint(1, 300))])
+        check(lib, [0] * rng.randint(1, 6), module, op, kw, rng.random() < 0.5, R=R, C=C, seed=seed,
+              missing_frac=rng.choice([0.0, 0.2, 0.7]), exchange_every=rng.randint(1, 5))
+
+
+def test_setup_and_statistics_random_shapes_oracle(oracle):
+    random_shapes(oracle, range(100))
+
+
+@pytest.mark.gpu
+def test_setup_and_statistics_random_shapes_hip(hip):
+    random_shapes(hip, range(100, 180))
