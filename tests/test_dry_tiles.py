@@ -95,3 +95,67 @@ def test_dry_tiles_across_slabs(hip, oracle, k):
             mds = [g.run_block(17, 1e-4), g.run_block(23, 1e-4)]
             res[name] = (g.download_water(), mds)
     assert bits_equal(res["hip"][0], res["oracle"][0]) and res["hip"][1] == res["oracle"][1]
+
+
+@pytest.mark.parametrize("module", ["add", "drain"])
+def test_random_ponds_and_call_sequences(hip, oracle, module):
+    """random rasters with a few ponds (so that whole tiles are dry and stay dry, or get wet later), random chunk heights,
+    random sequences of begin / iterate / expect / max_diff / upload_rows (water dropped into dry land) / volume / download
+    with tile skipping on: every observation equals the oracle's, and over the whole hunt tiles really were skipped"""
+    import random
+    import os
+    lo, hi = (int(v) for v in os.environ.get("WDPM_FUZZ_SEEDS", "0:40").split(":"))
+    seen = worked = 0
+    for seed in range(lo, hi):
+        rng = random.Random(seed * 2 + (module == "drain"))
+        nrng = np.random.default_rng(seed)
+        R, C = rng.randint(40, 330), rng.randint(150, 1300)
+        y, x = np.mgrid[0:R, 0:C]
+        dem = np.round(520.0 - 0.02 * x - 0.03 * y + 0.3 * np.sin(x / 7.0) * np.cos(y / 5.0) + 0.05 * nrng.random((R, C)), 4)
+        if rng.random() < 0.5:
+            dem[nrng.random((R, C)) < 0.03] = MISS
+        water = np.zeros((R, C))
+        for _ in range(rng.randint(0, 4)):
+            r, c = rng.randrange(R), rng.randrange(C)
+            water[r:r + rng.randint(1, 12), c:c + rng.randint(1, 40)] = 0.3 * rng.random() + 0.01
+        water[dem <= MISS] = 0.0
+        bd, bw = pad(dem, water, MISS)
+        ckw = dict(module=module, nrows=R, ncols=C, missingvalue=MISS)
+        if module == "drain":
+            dr, dc = find_drain(bd)
+            ckw.update(drainrow=dr, draincol=dc)
+        chunk = rng.choice([6, 6, 12, 30, 96, 0])
+        with hip.context(kernel=wdpm_amd.KERNEL_FUSED, chunk_rows=chunk, **ckw) as g, oracle.context(**ckw) as o:
+            if rng.random() < 0.3:
+                g.set_option(wdpm_amd.capi.OPT_SPARSE, 1)
+            for c in (g, o):
+                c.upload(bd, bw)
+                c.totaldrain = 0.0
+            for step in range(rng.randint(5, 12)):
+                op = rng.choice(["it", "it", "it", "begin", "rows", "maxdiff", "expect", "volume", "download"])
+                if op == "it":
+                    n = rng.randint(1, 6)
+                    g.iterate(n); o.iterate(n)
+                elif op == "begin":
+                    t = rng.choice([0.0, 1e-3])
+                    g.begin_block(t); o.begin_block(t)
+                elif op == "rows":
+                    n = rng.randint(1, 4); r0 = rng.randint(0, R + 2 - n)
+                    rows = np.zeros((n, C + 2))
+                    c0 = rng.randrange(C)
+                    rows[:, c0:c0 + rng.randint(1, 30)] = 0.2
+                    rows = np.where(bd[r0:r0 + n] > MISS, rows, 0.0)
+                    g.upload_rows(r0, rows); o.upload_rows(r0, rows)
+                elif op == "expect":
+                    g.expect_max_diff(0, R + 2); o.expect_max_diff(0, R + 2)
+                elif op == "maxdiff":
+                    assert g.max_diff() == o.max_diff(), (seed, step)
+                elif op == "volume":
+                    assert g.volume_partial(0, R + 2, 0.0) == o.volume_partial(0, R + 2, 0.0), (seed, step)
+                else:
+                    assert n_bit_diff(g.download_water(), o.download_water()) == 0, (seed, step, R, C, chunk)
+            assert n_bit_diff(g.download_water(), o.download_water()) == 0, (seed, R, C, chunk)
+            assert g.max_diff() == o.max_diff() and g.totaldrain == o.totaldrain
+            seen += g.get_option(wdpm_amd.capi.OPT_TILES_SEEN)
+            worked += g.get_option(wdpm_amd.capi.OPT_TILES_WORKED)
+    assert 0 < worked < 0.8 * seen, (worked, seen)
