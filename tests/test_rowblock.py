@@ -385,3 +385,36 @@ def test_random_group_jobs_equal_one_context(oracle):
 @pytest.mark.gpu
 def test_hip_random_group_jobs_equal_the_oracle(oracle, hip):
     _random_group_jobs(hip, oracle, range(2000, 2080))
+
+
+def test_partition_properties_on_random_inputs(oracle):
+    """wdpm_partition on 3000 random (rows, ranks, exchange interval, module, outlet row): whenever it accepts, the slabs tile
+    the padded rows, every boundary is = 2 (mod 3), every slab starts on a multiple of 3 and lies inside the raster, interior
+    halos have the full depth, and a drain outlet is at least three owned rows away from its owner's boundaries"""
+    import random
+    rng = random.Random(7)
+    accepted = 0
+    for _ in range(3000):
+        nrows = rng.choice([rng.randint(1, 60), rng.randint(60, 3000), rng.randint(3000, 70000)])
+        n, k = rng.randint(1, 16), rng.randint(1, 12)
+        module = rng.choice(["add", "drain"])
+        dr = rng.randint(1, nrows) if module == "drain" else -1
+        try:
+            slabs = partition(oracle, nrows, n, k, module, dr)
+        except ValueError:
+            continue
+        accepted += 1
+        up, down = halo_depth(k)
+        assert len(slabs) == n and slabs[0].own_lo == 0 and slabs[-1].own_hi == nrows + 1
+        for a, b in zip(slabs, slabs[1:]):
+            assert b.own_lo == a.own_hi + 1 and b.own_lo % 3 == 2, (nrows, n, k, module, dr)
+        for s in slabs:
+            assert s.own_lo <= s.own_hi and s.row0 % 3 == 0 and s.row0 >= 0 and s.row0 + s.rows <= nrows + 2
+            assert s.row0 <= s.own_lo - (s.up if s.rank > 0 else 0) and s.row0 + s.rows - 1 >= s.own_hi + (s.down if s.rank < n - 1 else 0)
+            if s.rank > 0:
+                assert s.up == up
+            if s.rank < n - 1:
+                assert s.down == min(down, nrows + 1 - s.own_hi)
+            if module == "drain" and s.own_lo <= dr <= s.own_hi and n > 1:
+                assert (s.rank == 0 or dr - s.own_lo >= 3) and (s.rank == n - 1 or s.own_hi - dr >= 3), (nrows, n, k, dr, s)
+    assert accepted > 1000
