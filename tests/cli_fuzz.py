@@ -31,7 +31,7 @@ def write_asc(path, a, nodata, rng, style):
             f.write(sep.join(fmt_val(rng, a[r, c], style["num"]) for c in range(C)) + (sep if style["trail"] else "") + eol)
         if style["blank"]: f.write(eol)
 
-def one(seed, work, ref_exe, exe):
+def one(seed, work, ref_exe, exe, vary_env=False):
     rng = random.Random(seed); nrng = np.random.default_rng(seed)
     rng_amt = random.Random(seed * 7 + 1).choice([5, 50, 250.5])
     R, C = (rng.randint(1, 14), rng.randint(1, 17)) if rng.random() < 0.85 else (rng.randint(20, 70), rng.randint(20, 90))
@@ -68,8 +68,20 @@ def one(seed, work, ref_exe, exe):
             with open(os.path.join(d, "params.txt"), "w") as f:
                 f.write("\n".join(args) + "\n")
             argv = ["params.txt"]
+        env = dict(os.environ)
+        for k in ("WDPM_DEVICES", "WDPM_GPUS", "WDPM_EXCHANGE_EVERY", "WDPM_SCRATCH_BINARY", "WDPM_IO_THREADS"):
+            env.pop(k, None)
+        if vary_env and name == "new":      # knobs of the product that must never show in the results
+            erng = random.Random(seed * 13 + 5)
+            if erng.random() < 0.6:
+                env["WDPM_DEVICES"] = ",".join(["0"] * erng.randint(2, 5))
+                env["WDPM_EXCHANGE_EVERY"] = str(erng.randint(1, 5))
+            if erng.random() < 0.4:
+                env["WDPM_SCRATCH_BINARY"] = "1"
+            env["WDPM_IO_THREADS"] = str(erng.choice([1, 2, 5]))
+            env["WDPM_HOST_PAR_MIN"] = "1"
         try:
-            p = subprocess.run([exe] + argv, cwd=d, capture_output=True, text=True, timeout=60, errors="replace")
+            p = subprocess.run([exe] + argv, cwd=d, capture_output=True, text=True, timeout=60, errors="replace", env=env)
             rc, out = p.returncode, p.stdout
         except subprocess.TimeoutExpired:
             rc, out = "timeout", ""

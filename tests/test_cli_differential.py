@@ -16,9 +16,9 @@ HIP_CLI = os.path.join(ROOT, "wdpm_amd", "bin", "WDPMCL")
 needs_ref = pytest.mark.skipif(not os.path.exists(REF_CLI), reason="oracle/_ref/WDPMCL_ref not built (needs /root/reference)")
 
 
-def differential(exe, seeds, tmp_path):
+def differential(exe, seeds, tmp_path, vary_env=False):
     for seed in seeds:
-        ok, ref, new, style, info = one(seed, str(tmp_path), REF_CLI, exe)
+        ok, ref, new, style, info = one(seed, str(tmp_path), REF_CLI, exe, vary_env)
         assert ok, (f"seed {seed} {info} {style}: exit codes {ref[0]} / {new[0]}, files {ref[2]} / {new[2]}, "
                     f"{first_difference(ref[1], new[1])}, args {ref[3]}")
         assert ref[0] == 0 and ref[2]["out.asc"] is not None          # the jobs are valid ones: the reference ran them
@@ -30,6 +30,14 @@ def test_cli_equals_the_reference_executable_on_random_jobs(oracle, tmp_path):
 
 
 @needs_ref
+def test_cli_knobs_never_show_in_the_results(oracle, tmp_path):
+    """the same jobs with the raster spread over 2-5 row blocks, other exchange intervals, threaded ArcASCII I/O and the
+    binary checkpoint sidecar switched on at random: still the reference's bytes"""
+    differential(ORACLE_CLI, range(300, 420), tmp_path, vary_env=True)
+
+
+@needs_ref
 @pytest.mark.gpu
 def test_hip_cli_equals_the_reference_executable_on_random_jobs(tmp_path):
     differential(HIP_CLI, range(1000, 1060), tmp_path)
+    differential(HIP_CLI, range(1300, 1360), tmp_path, vary_env=True)
