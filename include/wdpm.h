@@ -318,9 +318,12 @@ int  wdpm_group_enqueue_stats(wdpm_group *grp, double *seconds, double *exchange
  *   neither loads nor - when the output raster's block is known to hold zeros too - stores anything.  Results
  *   are identical either way.  WDPM_OPT_TILES_SEEN / _WORKED (get): tiles of flag-keeping launches and those
  *   among them that did work, summed at every wdpm_max_diff.  WDPM_OPT_SPARSE (get/set): the kernel marches
- *   short chunks because most tiles were dry in the last block (the library switches by itself). */
+ *   short chunks because most tiles were dry in the last block (the library switches by itself).
+ * WDPM_OPT_GUARD_BAD (get): with WDPM_GUARD_KB=<n> in the environment when the context was made, the big device buffers
+ *   carry n KiB guard bands; this counts guard bytes that were overwritten (0 = no kernel wrote outside its buffer; always 0
+ *   without the variable).  A debugging aid: the GPU pool has no address sanitizer. */
 enum { WDPM_OPT_SIGNED_ZERO_SAFE = 1, WDPM_OPT_DEM32 = 2, WDPM_OPT_TILES = 3, WDPM_OPT_TILES_SEEN = 4,
-       WDPM_OPT_TILES_WORKED = 5, WDPM_OPT_SPARSE = 6 };
+       WDPM_OPT_TILES_WORKED = 5, WDPM_OPT_SPARSE = 6, WDPM_OPT_GUARD_BAD = 7 };
 int wdpm_get_option(wdpm_ctx *ctx, int32_t key, int64_t *value);
 int wdpm_set_option(wdpm_ctx *ctx, int32_t key, int64_t value);
 

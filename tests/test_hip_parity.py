@@ -680,3 +680,28 @@ def test_drain_outlet_at_every_window_position(hip, oracle, chunk):
                     c.begin_block(1e-3)
                     c.iterate(2)
                 assert g.drain_stats() == o.drain_stats() and g.max_diff() == o.max_diff(), (dr, dc)
+
+
+def test_guard_bands_notice_a_stray_write(hip):
+    """the net the whole GPU suite runs in (tests/conftest.py: WDPM_GUARD_KB, checked whenever a context closes) does catch:
+    three bytes written just in front of the current water raster and two just behind its dump area are counted"""
+    import ctypes as C
+    assert int(os.environ.get("WDPM_GUARD_KB", "0")) > 0
+    R, Cc = 20, 30
+    with open("/proc/self/maps") as f:      # the HIP runtime this process already runs on (never a second one)
+        path = next(line.split()[-1] for line in f if "libamdhip64.so" in line)
+    rt = C.CDLL(path)
+    rt.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    c = hip.context(module="add", nrows=R, ncols=Cc, missingvalue=-99999.0)
+    try:
+        c.upload(np.full((R + 2, Cc + 2), 500.0), np.full((R + 2, Cc + 2), 0.1))
+        c.iterate(2)
+        assert c.get_option(wdpm_amd.capi.OPT_GUARD_BAD) == 0
+        p = c.water_ptr()
+        assert rt.hipMemset(p - 3, 0, 3) == 0
+        assert rt.hipMemset(p + ((R + 2) * (Cc + 2) + 64) * 8, 0, 2) == 0
+        assert rt.hipDeviceSynchronize() == 0
+        assert c.get_option(wdpm_amd.capi.OPT_GUARD_BAD) == 5
+    finally:
+        hip.dll.wdpm_destroy(c._h)          # not through close(): that one would (rightly) complain
+        c._h = None

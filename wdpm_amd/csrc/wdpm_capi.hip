@@ -140,6 +140,48 @@ static int ensure_fresh_slot(wdpm_ctx *x) {
   return 0;
 }
 
+/* Guard bands (debugging aid, WDPM_GUARD_KB=<n> in the environment when the context is made): the big device buffers - DEM,
+ * the three water rasters, the DEM codes, the tile flags - get n KiB of 0xA5 bytes in front and behind, and
+ * wdpm_get_option(WDPM_OPT_GUARD_BAD) counts guard bytes that no longer hold 0xA5: a kernel writing outside its raster shows up
+ * there even when the stray bytes land in nobody's data.  The GPU pool has no address sanitizer; the fuzz tests run with this on. */
+static size_t guard_bytes() {
+  static long kb = -1;
+  if (kb < 0) { const char *e = getenv("WDPM_GUARD_KB"); kb = e ? atol(e) : 0; if (kb < 0) kb = 0; }
+  return (size_t)kb * 1024;
+}
+static hipError_t guarded_malloc(wdpm_ctx *x, void **p, size_t bytes) {
+  const size_t g = guard_bytes();
+  char *base = nullptr;
+  hipError_t e = hipMalloc(&base, bytes + 2 * g);
+  if (e != hipSuccess) return e;
+  if (g) {
+    e = hipMemset(base, 0xA5, g);
+    if (e == hipSuccess) e = hipMemset(base + g + bytes, 0xA5, g);
+    if (e != hipSuccess) { (void)hipFree(base); return e; }
+    x->guards.push_back({base, bytes});
+  }
+  *p = base + g;
+  return hipSuccess;
+}
+static void guarded_free(void *p) {
+  if (p) (void)hipFree(static_cast<char *>(p) - guard_bytes());
+}
+static int guard_damage(wdpm_ctx *x, int64_t *bad) {
+  *bad = 0;
+  const size_t g = guard_bytes();
+  if (!g || x->guards.empty()) return 0;
+  if (bind(x)) return 1;
+  HIP_TRY(hipStreamSynchronize(x->stream));
+  if (x->side) HIP_TRY(hipStreamSynchronize(x->side));
+  std::vector<unsigned char> h(g);
+  for (const auto &gb : x->guards)
+    for (int side = 0; side < 2; side++) {
+      HIP_TRY(hipMemcpy(h.data(), gb.base + (side ? g + gb.bytes : 0), g, hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < g; i++) *bad += h[i] != 0xA5;
+    }
+  return 0;
+}
+
 int wdpm_create(wdpm_ctx **out, const wdpm_params *p) {
   if (!out || !p) return fail("wdpm_create: null argument");
   if (p->nrows < 1 || p->ncols < 1) return fail("wdpm_create: bad raster size %d x %d", p->nrows, p->ncols);
@@ -212,19 +254,19 @@ int wdpm_create(wdpm_ctx **out, const wdpm_params *p) {
   if (e == hipSuccess) e = hipStreamCreateWithPriority(&x->side, hipStreamNonBlocking, prio_least);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&x->ev_fork, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&x->ev_join, hipEventDisableTiming);
-  if (e == hipSuccess) e = hipMalloc(&x->d_dem, bytes);
+  if (e == hipSuccess) e = guarded_malloc(x, (void **)&x->d_dem, bytes);
   /* + 64 doubles behind each water raster: the fused kernel's dump area for masked-out stores */
-  if (e == hipSuccess) e = hipMalloc(&x->d_w[0], bytes + 64 * sizeof(double));
-  if (e == hipSuccess) e = hipMalloc(&x->d_w[1], bytes + 64 * sizeof(double));
-  if (e == hipSuccess) e = hipMalloc(&x->d_w[2], bytes + 64 * sizeof(double));
-  if (e == hipSuccess) e = hipMalloc(&x->d_dem32, x->cells * sizeof(int) + 64);
+  if (e == hipSuccess) e = guarded_malloc(x, (void **)&x->d_w[0], bytes + 64 * sizeof(double));
+  if (e == hipSuccess) e = guarded_malloc(x, (void **)&x->d_w[1], bytes + 64 * sizeof(double));
+  if (e == hipSuccess) e = guarded_malloc(x, (void **)&x->d_w[2], bytes + 64 * sizeof(double));
+  if (e == hipSuccess) e = guarded_malloc(x, (void **)&x->d_dem32, x->cells * sizeof(int) + 64);
   if (e == hipSuccess) e = hipMalloc(&x->d_scal, 2 * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&x->d_bits, sizeof(unsigned long long));
   if (e == hipSuccess) e = hipMalloc(&x->d_md, sizeof(unsigned long long));
   {
     /* tile flags: strips of 171 columns x chunks of >= 6 rows */
     x->tile_cap = (x->g.ncp / 171 + 4) * (rows / 6 + 4);
-    for (int i = 0; i < 3 && e == hipSuccess; i++) e = hipMalloc(&x->d_zero[i], (size_t)x->tile_cap);
+    for (int i = 0; i < 3 && e == hipSuccess; i++) e = guarded_malloc(x, (void **)&x->d_zero[i], (size_t)x->tile_cap);
     if (e == hipSuccess) e = hipMalloc(&x->d_active, sizeof(unsigned));
     if (e == hipSuccess) e = hipHostMalloc(&x->h_active, sizeof(unsigned));
     if (e == hipSuccess) e = hipMemsetAsync(x->d_active, 0, sizeof(unsigned), x->stream);
@@ -255,9 +297,9 @@ void wdpm_destroy(wdpm_ctx *x) {
   for (auto &ep : x->pending) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
   for (auto &ep : x->pending_steady) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
   for (auto &ep : x->pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
-  (void)hipFree(x->d_dem); (void)hipFree(x->d_w[0]); (void)hipFree(x->d_w[1]); (void)hipFree(x->d_w[2]);
-  (void)hipFree(x->d_scal); (void)hipFree(x->d_bits); (void)hipFree(x->d_dem32); (void)hipFree(x->d_stat);
-  for (int i = 0; i < 3; i++) (void)hipFree(x->d_zero[i]);
+  guarded_free(x->d_dem); guarded_free(x->d_w[0]); guarded_free(x->d_w[1]); guarded_free(x->d_w[2]);
+  (void)hipFree(x->d_scal); (void)hipFree(x->d_bits); guarded_free(x->d_dem32); (void)hipFree(x->d_stat);
+  for (int i = 0; i < 3; i++) guarded_free(x->d_zero[i]);
   (void)hipFree(x->d_active);
   (void)hipFree(x->d_md);
   if (x->h_active) (void)hipHostFree(x->h_active);
@@ -540,6 +582,7 @@ int wdpm_get_option(wdpm_ctx *x, int32_t key, int64_t *value) {
   else if (key == WDPM_OPT_TILES_SEEN) *value = x->stat_tiles;
   else if (key == WDPM_OPT_TILES_WORKED) *value = x->stat_active;
   else if (key == WDPM_OPT_SPARSE) *value = x->sparse ? 1 : 0;
+  else if (key == WDPM_OPT_GUARD_BAD) return guard_damage(x, value);
   else return fail("wdpm_get_option: unknown option %d", key);
   return 0;
 }

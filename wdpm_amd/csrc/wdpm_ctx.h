@@ -55,6 +55,8 @@ struct wdpm_ctx {
   unsigned *d_sum_flag;
   int kernel;                   /* resolved WDPM_KERNEL_* */
   bool signed_zero_safe;        /* a -0.0 depth was uploaded (or the caller asked): exact-zero stencil variant */
+  struct GuardedBuffer { char *base; size_t bytes; };   /* base = start of the front guard band; bytes = payload between the bands */
+  std::vector<GuardedBuffer> guards;   /* WDPM_GUARD_KB: the buffers wdpm_get_option(WDPM_OPT_GUARD_BAD) inspects */
   int *d_dem32;                 /* the DEM as verified-lossless 32-bit codes (wdpm_kernels.h::DemCode) */
   DemCode code;                 /* code.q == d_dem32 while the uploaded DEM is encodable and the option is on */
   bool dem32_encodable;

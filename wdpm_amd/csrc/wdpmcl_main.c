@@ -817,7 +817,17 @@ int main(int argc, char **argv) {
   ABI_TRY(wdpm_group_count_stats(ctx, NULL, &wet, &dev_max));
   ABI_TRY(wdpm_group_download_unpadded(ctx, 1, st.water));
   if (cfg.module == WDPM_DRAIN) ABI_TRY(wdpm_group_get_totaldrain(ctx, &totaldrain));
+  int64_t guard_bad = 0;
+  if (getenv("WDPM_GUARD_KB")) {   /* debugging aid (include/wdpm.h: WDPM_OPT_GUARD_BAD): did any kernel write outside its buffer? */
+    for (int i = 0; i < ndev; i++) {
+      int64_t bad = 0;
+      ABI_TRY(wdpm_get_option(wdpm_rank_ctx(wdpm_group_rank(ctx, i)), WDPM_OPT_GUARD_BAD, &bad));
+      guard_bad += bad;
+    }
+    fprintf(stderr, "WDPMCL: guard bands of %d slab%s: %lld bytes overwritten\n", ndev, ndev == 1 ? "" : "s", (long long)guard_bad);
+  }
   wdpm_group_destroy(ctx);
+  if (guard_bad) return 3;
   phase("statistics + download + destroy");
 
   const int watercount = (int)wet;
