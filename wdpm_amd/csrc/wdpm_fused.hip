@@ -470,8 +470,17 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
                    : "memory");                                                                        \
   } while (0)
 
-    // the three staged rows [rb, rb+2] from LDS to HBM: 9 unconditional stores
-    auto store_rows = [&](const int rb) {
+    // the three staged rows [rb, rb+2] from LDS to HBM: 9 unconditional stores.  In two halves: the LDS reads go out at
+    // the very top of a step, ahead of the decode work, so that their round trip is over when the stores want the values
+    // (issued right in front of the stores, each step stalled on it: +0.4 % at 8192^2, profiles/r02/early_lds_ab.txt)
+    double staged[3][3];
+    auto read_staged = [&]() {
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) staged[i][k] = stage_lds[i * kStripIn + scol[k]];
+    };
+    auto write_staged = [&](const int rb) {
 #pragma unroll
       for (int i = 0; i < 3; i++) {
         const int r = rb + i;
@@ -479,15 +488,13 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
         // rows outside the chunk's output range (first / last trips only) go to the dump area
         double *const orow = wout + (size_t)(row_ok ? r : 0) * pitch + c0;
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-          const double v = stage_lds[i * kStripIn + scol[k]];
-          __builtin_nontemporal_store(v, row_ok ? orow + scol[k] : dump);
-        }
+        for (int k = 0; k < 3; k++) __builtin_nontemporal_store(staged[i][k], row_ok ? orow + scol[k] : dump);
       }
       __builtin_amdgcn_wave_barrier();
     };
 
     auto step = [&](const int n, Prefetched &P) {
+      read_staged();
       // consume the prefetched rows into window slots 4..6; the device DEM already holds +inf for
       // NODATA cells, so only edge waves have anything to mask (outside the slab: dem=+inf, w=0)
 #pragma unroll
@@ -523,7 +530,7 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
       prefetch(P, A + 3 * (n + 1));
       // the rows the previous step staged in LDS go out now, behind the new loads and ahead of a
       // whole step of arithmetic (+1 % over storing at the end of the step); n = 0 has none: dump
-      store_rows(A + 3 * (n - 1) - 4);
+      write_staged(A + 3 * (n - 1) - 4);
 
       const int rbase = A + 3 * n - 4;                 // slab row of window slot 0
 #ifndef WDPM_ABLATE_COMPUTE                            /* timing experiments only: memory pattern alone */
@@ -536,7 +543,7 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
       // rows 3n-4 .. 3n-2 have now seen all nine passes.  The wave transposes each row through its
       // private LDS slice (no barrier: a wave's LDS operations complete in order) so that every
       // store instruction writes 512 contiguous bytes, streamed past the L2 (non-temporal); the
-      // stores themselves are issued by store_rows() at the top of the next step.
+      // stores themselves are issued by write_staged() at the top of the next step.
       if (MD) {
         // rows 3n-4 .. 3n-2 are final: their part of the block's max-change reduction, against the snapshot
         // (which may still be owed the block's flush: applied as it is read).  Only cells of this wave's own
@@ -582,7 +589,8 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
     prefetch(P, A);
     WDPM_WAIT_ROWS(0);
     for (int n = 0; n < nsteps; n++) step(n, P);
-    store_rows(A + 3 * (nsteps - 1) - 4);      // the last step's rows
+    read_staged();
+    write_staged(A + 3 * (nsteps - 1) - 4);    // the last step's rows
 #undef WDPM_WAIT_ROWS
 #undef WDPM_WAIT_W
   };
