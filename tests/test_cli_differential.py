@@ -39,5 +39,6 @@ def test_cli_knobs_never_show_in_the_results(oracle, tmp_path):
 @needs_ref
 @pytest.mark.gpu
 def test_hip_cli_equals_the_reference_executable_on_random_jobs(tmp_path):
-    differential(HIP_CLI, range(1000, 1060), tmp_path)
-    differential(HIP_CLI, range(1300, 1360), tmp_path, vary_env=True)
+    lo, hi = (int(v) for v in os.environ.get("WDPM_FUZZ_SEEDS", "1000:1060").split(":"))
+    differential(HIP_CLI, range(lo, hi), tmp_path)
+    differential(HIP_CLI, range(lo + 300, hi + 300), tmp_path, vary_env=True)

@@ -384,7 +384,8 @@ def test_random_group_jobs_equal_one_context(oracle):
 
 @pytest.mark.gpu
 def test_hip_random_group_jobs_equal_the_oracle(oracle, hip):
-    _random_group_jobs(hip, oracle, range(2000, 2080))
+    lo, hi = (int(v) for v in os.environ.get("WDPM_FUZZ_SEEDS", "2000:2080").split(":"))       # a longer hunt: WDPM_FUZZ_SEEDS=lo:hi
+    _random_group_jobs(hip, oracle, range(lo, hi))
 
 
 def test_partition_properties_on_random_inputs(oracle):

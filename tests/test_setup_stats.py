@@ -101,4 +101,6 @@ def test_setup_and_statistics_random_shapes_oracle(oracle):
 
 @pytest.mark.gpu
 def test_setup_and_statistics_random_shapes_hip(hip):
-    random_shapes(hip, range(100, 180))
+    import os
+    lo, hi = (int(v) for v in os.environ.get("WDPM_FUZZ_SEEDS", "100:180").split(":"))
+    random_shapes(hip, range(lo, hi))

@@ -1,0 +1,7 @@
+#!/bin/bash
+# A long hunt with the randomised GPU tests (seeds far outside the ranges the suite runs): usage on the GPU box: bash tools/fuzz_hunt.sh <lo> <hi>
+cd $GRAFT_REPO_ROOT; lo=${1:-10000}; hi=${2:-14000}; mkdir -p gpurun_out
+for t in "tests/test_hip_parity.py -k random_call" "tests/test_dry_tiles.py -k random_ponds" "tests/test_rowblock.py -k hip_random_group" "tests/test_setup_stats.py -k random_shapes_hip" "tests/test_hip_parity.py -k adversarial"; do
+  echo "== $t seeds $lo:$hi"; WDPM_FUZZ_SEEDS=$lo:$hi timeout -k 10 900 python -m pytest $t -m gpu -q -x 2>&1 | tail -n 6
+done
+echo "== CLI differential seeds $lo:$((lo + 400))"; WDPM_FUZZ_SEEDS=$lo:$((lo + 400)) timeout -k 10 900 python -m pytest tests/test_cli_differential.py -m gpu -q -x 2>&1 | tail -n 6
