@@ -19,6 +19,8 @@ needs_ref = pytest.mark.skipif(not os.path.exists(REF_CLI), reason="oracle/_ref/
 def differential(exe, seeds, tmp_path, vary_env=False):
     for seed in seeds:
         ok, ref, new, style, info = one(seed, str(tmp_path), REF_CLI, exe, vary_env)
+        if isinstance(ref[0], int) and ref[0] < 0:
+            continue      # the reference itself died of a signal on this job (seen once in 10 000: a 4 x 1 drain job): nothing to equal
         assert ok, (f"seed {seed} {info} {style}: exit codes {ref[0]} / {new[0]}, files {ref[2]} / {new[2]}, "
                     f"{first_difference(ref[1], new[1])}, args {ref[3]}")
         assert ref[0] == 0 and ref[2]["out.asc"] is not None          # the jobs are valid ones: the reference ran them

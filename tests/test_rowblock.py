@@ -419,3 +419,53 @@ def test_partition_properties_on_random_inputs(oracle):
             if module == "drain" and s.own_lo <= dr <= s.own_hi and n > 1:
                 assert (s.rank == 0 or dr - s.own_lo >= 3) and (s.rank == n - 1 or s.own_hi - dr >= 3), (nrows, n, k, dr, s)
     assert accepted > 1000
+
+
+def _outlet_on_a_slab_edge_cases(lib):
+    """(R, n, k, dr) with the outlet's row = the last (or first) row of a slab that does not own it: there the slab's kernels
+    cannot apply drain() to their copy of the outlet's 3x3 (it is cut by the slab edge), so the rows must ARRIVE drained"""
+    cases = []
+    for R, n, k in [(14, 2, 1), (40, 2, 2), (60, 3, 2), (90, 3, 3), (33, 2, 1), (120, 4, 2)]:
+        for dr in range(1, R + 1):
+            try:
+                slabs = partition(lib, R, n, k, "drain", dr)
+            except ValueError:
+                continue
+            for s in slabs:
+                owns = s.own_lo <= dr <= s.own_hi
+                if not owns and dr in (s.row0, s.row0 + s.rows - 1):
+                    cases.append((R, n, k, dr))
+    return cases
+
+
+def _check_outlet_on_slab_edges(lib, oracle):
+    cases = _outlet_on_a_slab_edge_cases(oracle)
+    assert len(cases) >= 8
+    for R, n, k, dr in cases:
+        C = 53
+        dem, water, miss = random_case(R * 100 + dr, R, C, missing_frac=0.0)
+        bd, bw = pad(dem, water, miss)
+        for dc in (1, 27, C):
+            kw = dict(drainrow=dr, draincol=dc)
+            with oracle.context(module="drain", nrows=R, ncols=C, missingvalue=miss, **kw) as c:
+                c.upload(bd, bw)
+                c.totaldrain = 0.1
+                want = [c.run_block(i, 1e-5) for i in (4, 9)]
+                w1, td1 = c.download_water(), c.totaldrain
+            with Group(lib, "drain", R, C, miss, [0] * n, exchange_every=k, **kw) as g:
+                g.upload(bd, bw)
+                g.set_totaldrain(0.1)
+                got = [g.run_block(i, 1e-5) for i in (4, 9)]
+                assert got == want and g.totaldrain() == td1, (R, n, k, dr, dc)
+                assert n_bit_diff(g.download_water(), w1) == 0, (R, n, k, dr, dc)
+
+
+def test_outlet_on_the_edge_row_of_a_neighbours_slab(oracle):
+    _check_outlet_on_slab_edges(oracle, oracle)
+
+
+@pytest.mark.gpu
+def test_hip_outlet_on_the_last_row_of_the_neighbours_halo(oracle, hip):
+    """found by the long fuzz hunt (seed 12601): rows sent to a neighbour did not carry the owed drain(), and a slab whose
+    last row is the outlet's row never applies its own"""
+    _check_outlet_on_slab_edges(hip, oracle)

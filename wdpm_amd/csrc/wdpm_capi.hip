@@ -48,6 +48,8 @@ int wdpm_fail(const char *fmt, ...) {
 struct wdpm_ctx;
 static int tiles_touch(wdpm_ctx *x, int slot, int row, int nrows);
 int wdpm_tiles_touch(wdpm_ctx *x, int row, int nrows) { return tiles_touch(x, x->cur, row, nrows); }
+static int ensure_drained(wdpm_ctx *x);
+int wdpm_apply_owed_drain(wdpm_ctx *x) { return ensure_drained(x); }
 
 extern "C" {
 
@@ -557,6 +559,10 @@ int wdpm_copy_rows(wdpm_ctx *dst, int32_t dst_row, wdpm_ctx *src, int32_t src_ro
    * turn waits for the copy to have read them.  With N devices in a chain the halo refresh is then
    * 2(N-1) enqueues and no host round trip. */
   if (bind(src)) return 1;                       /* also joins a pending overlapped interior launch */
+  /* Rows that leave a context carry the last iteration's drain(): the receiver applies its own owed drain() only where the
+   * outlet lies strictly inside ITS slab - not when the outlet's row is the slab's first or last row, and then the nine
+   * cells must arrive zeroed (tests/test_rowblock.py::test_hip_outlet_on_the_last_row_of_the_neighbours_halo). */
+  if (ensure_drained(src)) return 1;
   if (!src->ev_copy[0]) HIP_TRY(hipEventCreateWithFlags(&src->ev_copy[0], hipEventDisableTiming));
   HIP_TRY(hipEventRecord(src->ev_copy[0], src->stream));
   if (bind(dst)) return 1;

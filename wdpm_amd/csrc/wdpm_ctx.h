@@ -83,5 +83,6 @@ struct wdpm_ctx {
 int wdpm_fail(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
 void wdpm_comm_release(wdpm_ctx *x);   /* wdpm_destroy's hook */
 int wdpm_tiles_touch(wdpm_ctx *x, int row, int nrows);   /* rows of the current raster written from outside: dry-tile flags */
+int wdpm_apply_owed_drain(wdpm_ctx *x);   /* drain module: the last iteration's drain() if it has not been applied yet (before rows leave the context) */
 
 #endif

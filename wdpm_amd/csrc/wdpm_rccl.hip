@@ -199,6 +199,7 @@ int wdpm_comm_exchange(wdpm_ctx *x, int32_t nsend, const wdpm_halo_op *sends, in
         return wdpm_fail("wdpm_comm_exchange: bad row range or peer");
   }
   HIP_TRY(hipSetDevice(x->p.device));
+  if (nsend > 0 && wdpm_apply_owed_drain(x)) return 1;   /* rows that leave carry the last iteration's drain() (see wdpm_copy_rows) */
   for (int i = 0; i < nrecv; i++)
     if (wdpm_tiles_touch(x, recvs[i].row, recvs[i].nrows)) return 1;   /* received rows: those tiles are no longer known dry */
   double *w = x->d_w[x->cur];
