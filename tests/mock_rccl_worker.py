@@ -47,3 +47,12 @@ for module, R, C, n, k, blocks in (("add", 300, 420, 3, 3, [13, 8]), ("add", 260
     assert res["one"][1] == res["many"][1], (module, n, k, res["one"][1], res["many"][1])
     n_ok += 1
 print("MOCK_RCCL_GROUPS_OK", n_ok)
+
+# the random row-block jobs of tests/test_rowblock.py (2-7 slabs, any module, outlet anywhere, every slab-edge geometry of the
+# outlet) once more with the halos going through wdpm_comm_exchange instead of peer copies, against the oracle
+from test_rowblock import _check_outlet_on_slab_edges, _random_group_jobs   # noqa: E402
+oracle = wdpm_amd.load(os.path.join(ROOT, "oracle", "_build", "libwdpm_oracle.so"))
+lo, hi = (int(v) for v in os.environ.get("WDPM_FUZZ_SEEDS", "3000:3060").split(":"))
+_random_group_jobs(hip, oracle, range(lo, hi))
+_check_outlet_on_slab_edges(hip, oracle)
+print("MOCK_RCCL_RANDOM_JOBS_OK", hi - lo)

@@ -26,6 +26,7 @@ def test_groups_with_rccl_halos_equal_one_context(mock_env):
                        capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     assert "MOCK_RCCL_GROUPS_OK 5" in p.stdout, p.stdout + p.stderr[-2000:]
+    assert "MOCK_RCCL_RANDOM_JOBS_OK" in p.stdout, p.stdout + p.stderr[-2000:]
 
 
 def test_cli_on_three_slabs_with_rccl_halos(mock_env, tmp_path):
