@@ -16,13 +16,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <vector>
 
 #include "wdpm_ctx.h"
 
 /* chunk height of the iteration kernel once most tiles are dry (WDPM_SPARSE_ROWS overrides: tuning) */
 static int sparse_chunk_rows() {
-  static int v = 0;
+  static std::atomic<int> v{0};
   if (!v) { const char *e = getenv("WDPM_SPARSE_ROWS"); v = e && atoi(e) >= 6 ? atoi(e) / 3 * 3 : 96; }
   return v;
 }
@@ -147,7 +148,7 @@ static int ensure_fresh_slot(wdpm_ctx *x) {
  * wdpm_get_option(WDPM_OPT_GUARD_BAD) counts guard bytes that no longer hold 0xA5: a kernel writing outside its raster shows up
  * there even when the stray bytes land in nobody's data.  The GPU pool has no address sanitizer; the fuzz tests run with this on. */
 static size_t guard_bytes() {
-  static long kb = -1;
+  static std::atomic<long> kb{-1};
   if (kb < 0) { const char *e = getenv("WDPM_GUARD_KB"); kb = e ? atol(e) : 0; if (kb < 0) kb = 0; }
   return (size_t)kb * 1024;
 }

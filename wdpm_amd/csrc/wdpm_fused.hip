@@ -40,6 +40,7 @@
 #include "wdpm_kernels.h"
 #include "wdpm_stencil.h"
 
+#include <atomic>
 #include <cstdlib>
 #include <type_traits>
 
@@ -903,20 +904,20 @@ __global__ void dpp_probe_kernel(int *out) {
  * together — one round, no tail — so the item count is sized to this. */
 template <int MODULE, bool SZ_SAFE, bool DEM32 = false>
 static int resident_waves() {
-  static int cached = 0;
-  if (cached) return cached;
+  static std::atomic<int> cached{0};      // rank threads of one process launch concurrently: no plain statics
+  if (cached.load(std::memory_order_relaxed)) return cached.load(std::memory_order_relaxed);
   int dev = 0, cus = 256, blocks = 2;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, fused_iteration_kernel<MODULE, SZ_SAFE, DEM32>, 256, 0) != hipSuccess || blocks < 1)
     blocks = 2;
-  cached = cus * blocks * 4;
-  return cached;
+  cached.store(cus * blocks * 4, std::memory_order_relaxed);
+  return cus * blocks * 4;
 }
 
 /* chunk height in rows (multiple of 3): the rows are cut into as many chunks as keep
  * strips x chunks within one resident round; each chunk pays a 6-row warm-up. */
 static int pick_chunk_rows(const int rows, const int nstrips, const int override_rows, const int slots) {
-  static int env_h = -1;
+  static std::atomic<int> env_h{-1};
   if (env_h < 0) {
     const char *e = getenv("WDPM_CHUNK_ROWS");
     env_h = e ? atoi(e) : 0;
@@ -941,7 +942,7 @@ static int pick_chunk_rows(const int rows, const int nstrips, const int override
 }
 
 static hipError_t dpp_selfcheck(hipStream_t s) {
-  static int state = 0;   // 0 unknown, 1 ok, -1 bad
+  static std::atomic<int> state{0};   // 0 unknown, 1 ok, -1 bad
   if (state == 1) return hipSuccess;
   if (state == -1) return hipErrorUnknown;
   int *d = nullptr;
@@ -986,7 +987,7 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
     // Small launches: if every 3-row chunk of the window fits on the chip at once, the triangle kernel's six
     // lockstep stages beat the marching kernel's nine dependent ones (482 x 471: DESIGN.md §4.1c).
     // WDPM_TRI=0 keeps the marching kernel (A/B runs), WDPM_TRI=2 forces the triangle kernel on any size.
-    static int env_tri = -1, tri_slots = 0;
+    static std::atomic<int> env_tri{-1}, tri_slots{0};
     if (env_tri < 0) { const char *t = getenv("WDPM_TRI"); env_tri = t ? atoi(t) : 1; }
     if (!tri_slots) {
       int dev = 0, cus = 256, blocks = 1;
@@ -1032,7 +1033,7 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
     // lane leave it latency-bound (59 % VALU issue at one wave per SIMD), and a second wave per SIMD
     // fills the bubbles: +21 % at 8192^2, +30 % at 16384^2 - as long as the chunks stay tall enough
     // for the 6-row warm-up of each not to eat the gain.
-    static int env_pct = -1;
+    static std::atomic<int> env_pct{-1};
     if (env_pct < 0) { const char *e = getenv("WDPM_FILL_PERCENT"); env_pct = e ? atoi(e) : 0; }
     // With the DEM as 32-bit codes the add kernel is in the same position: fewer bytes, nine decodes
     // more per step - one wave per SIMD 1.34 ms per 16384^2 launch (no gain), two waves 1.23 ms.
