@@ -390,6 +390,15 @@ def test_degenerate_shapes(hip, oracle, R, C):
     _compare_with_oracle(hip, oracle, "drain", R, C, seed=R * 7 + C + 1, iters=(4,), kernel=wdpm_amd.KERNEL_FUSED)
 
 
+def test_every_width_around_strip_boundaries(hip, oracle):
+    """every raster width from 165 to 200, 335 to 350 and 505 to 520 columns (a strip stores 171 columns and loads 192: widths
+    that end a strip exactly, one short, one over, inside the halo ...), marching kernel (12-row chunks) and triangle kernel"""
+    for C in list(range(165, 201)) + list(range(335, 351)) + list(range(505, 521)):
+        for R, chunk in ((9, 0), (26, 12)):
+            _compare_with_oracle(hip, oracle, "add", R, C, seed=C * 3 + R, iters=(2,), kernel=wdpm_amd.KERNEL_FUSED, chunk=chunk)
+        _compare_with_oracle(hip, oracle, "drain", 14, C, seed=C * 5, iters=(2,), kernel=wdpm_amd.KERNEL_FUSED, chunk=12 if C % 2 else 0)
+
+
 @pytest.mark.parametrize("R,C", [(2, 50000), (50000, 2), (7, 30000), (30000, 7), (1, 100000), (100000, 1)])
 def test_extreme_aspect_ratios(hip, oracle, R, C):
     """hundreds of strips one chunk high, and one strip thousands of chunks high: the launch geometry at its ends
