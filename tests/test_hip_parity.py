@@ -399,6 +399,15 @@ def test_every_width_around_strip_boundaries(hip, oracle):
         _compare_with_oracle(hip, oracle, "drain", 14, C, seed=C * 5, iters=(2,), kernel=wdpm_amd.KERNEL_FUSED, chunk=12 if C % 2 else 0)
 
 
+def test_every_height_around_chunk_boundaries(hip, oracle):
+    """every raster height from 1 to 45 rows with the triangle kernel, 6-row and 12-row marching chunks (a chunk's last step,
+    the warm-up rows of the next, the raster's last rows in every position of the 3-row cadence), add and drain"""
+    for R in range(1, 46):
+        for chunk in (0, 6, 12):
+            _compare_with_oracle(hip, oracle, "add", R, 200, seed=R * 7 + chunk, iters=(3,), kernel=wdpm_amd.KERNEL_FUSED, chunk=chunk)
+        _compare_with_oracle(hip, oracle, "drain", R, 75, seed=R * 11, iters=(2,), kernel=wdpm_amd.KERNEL_FUSED, chunk=(0, 6, 12)[R % 3])
+
+
 @pytest.mark.parametrize("R,C", [(2, 50000), (50000, 2), (7, 30000), (30000, 7), (1, 100000), (100000, 1)])
 def test_extreme_aspect_ratios(hip, oracle, R, C):
     """hundreds of strips one chunk high, and one strip thousands of chunks high: the launch geometry at its ends

@@ -469,3 +469,30 @@ def test_hip_outlet_on_the_last_row_of_the_neighbours_halo(oracle, hip):
     """found by the long fuzz hunt (seed 12601): rows sent to a neighbour did not carry the owed drain(), and a slab whose
     last row is the outlet's row never applies its own"""
     _check_outlet_on_slab_edges(hip, oracle)
+
+
+def _every_height_in_slabs(lib, oracle):
+    """every raster height from 20 to 75 rows on 2 and 3 slabs with a refresh every 1 and 2 iterations: each boundary position of
+    the 3-row cadence, slabs of every size down to the smallest the partition accepts"""
+    for R in range(20, 76):
+        for n, k in ((2, 1), (3, 1), (2, 2)):
+            C = 40 + R % 7
+            dem, water, miss = random_case(R * 13 + n, R, C)
+            bd, bw = pad(dem, water, miss)
+            with oracle.context(module="add", nrows=R, ncols=C, missingvalue=miss) as c:
+                c.upload(bd, bw)
+                want = [c.run_block(i, 1e-5) for i in (3, 4)]
+                w1 = c.download_water()
+            with Group(lib, "add", R, C, miss, [0] * n, exchange_every=k) as g:
+                g.upload(bd, bw)
+                assert [g.run_block(i, 1e-5) for i in (3, 4)] == want, (R, n, k, g.size)
+                assert n_bit_diff(g.download_water(), w1) == 0, (R, n, k, g.size)
+
+
+def test_every_height_in_slabs(oracle):
+    _every_height_in_slabs(oracle, oracle)
+
+
+@pytest.mark.gpu
+def test_hip_every_height_in_slabs(oracle, hip):
+    _every_height_in_slabs(hip, oracle)
