@@ -67,3 +67,18 @@ def test_bench_group_driver():
     c = d["config"]
     assert d["n_gpus"] == 3 and c["driver"] == "group" and c["halo"] == "peer"
     assert c["enqueue_us_per_iteration_per_rank"] > 0
+
+
+def test_bench_ranks_fall_back_together_when_real_rccl_refuses():
+    """Two ranks on the ONE GPU of the test box with RCCL halos forced: both processes take the id rank 0 made, both call
+    ncclCommInitRank of the real RCCL - which refuses two ranks on one device - and then ALL ranks switch to host-staged halos
+    together and finish.  (As far as one GPU can take the process-per-rank RCCL path.)"""
+    env = dict(os.environ, WDPM_DIST_BACKEND="gloo", WDPM_HALO="rccl")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "1536", "--steps", "12", "--warmup", "3",
+                        "--exchange-every", "2", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][-1])
+    assert "RCCL halos refused" in p.stderr and "CommInitRank" in p.stderr
+    assert d["n_gpus"] == 2 and d["config"]["halo"].startswith("host") and d["value"] > 0
+    one = run_bench("--size", "1536", "--steps", "12", "--warmup", "3", "--no-cpu-baseline")
+    assert one["config"]["max_diff_m"] == d["config"]["max_diff_m"]
