@@ -82,3 +82,15 @@ def test_bench_ranks_fall_back_together_when_real_rccl_refuses():
     assert d["n_gpus"] == 2 and d["config"]["halo"].startswith("host") and d["value"] > 0
     one = run_bench("--size", "1536", "--steps", "12", "--warmup", "3", "--no-cpu-baseline")
     assert one["config"]["max_diff_m"] == d["config"]["max_diff_m"]
+
+
+def test_bench_launcher_starts_the_ranks_again_when_the_nccl_backend_fails():
+    """the same two ranks with torch.distributed's nccl backend forced as well: that backend itself fails on a shared device,
+    the rank processes die - and bench.py's own launcher starts them once more with host-staged halos over gloo"""
+    env = dict(os.environ, WDPM_DIST_BACKEND="nccl", WDPM_HALO="rccl", WDPM_BENCH_RANKS_TIMEOUT="200")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "1536", "--steps", "12", "--warmup", "3",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "starting them again with host-staged halos over gloo" in p.stderr
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][-1])
+    assert d["n_gpus"] == 2 and d["config"]["halo"] == "host" and d["config"]["dist_backend"] == "gloo" and d["value"] > 0
