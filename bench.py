@@ -202,6 +202,9 @@ def main():
     if args.gpus > 1 and not launched and args.driver == "ranks":
         sys.exit(self_launch(args))
 
+    # multi-process GPU work on this driver needs dmabuf IPC (RCCL, tensors shared across processes); exported on the pool's
+    # boxes already - set here too, before the runtime is loaded, for a shell that lacks it
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import wdpm_amd
     from wdpm_amd.rowblock import Group, HostTransport, RowBlockSolver
