@@ -390,6 +390,21 @@ def test_degenerate_shapes(hip, oracle, R, C):
     _compare_with_oracle(hip, oracle, "drain", R, C, seed=R * 7 + C + 1, iters=(4,), kernel=wdpm_amd.KERNEL_FUSED)
 
 
+@pytest.mark.parametrize("R,C", [(1250, 1300), (1700, 950), (700, 2900)])
+def test_triangle_kernel_in_several_rounds(hip, oracle, R, C):
+    """rasters whose 3-row chunks no longer fit on the chip at once but which the launcher still gives to the triangle kernel
+    (up to 2.2 rounds of waves, 2.7 for drain): 3 300 - 6 600 work items here, against the oracle, flush and max change included"""
+    # the first block runs on the marching kernel (it keeps the dry-tile flags and so finds out that the raster is mostly wet),
+    # the blocks after it on the triangle kernel; with tile tracking off the triangle kernel runs from the first launch
+    _compare_with_oracle(hip, oracle, "add", R, C, seed=R + C, iters=(2, 2, 1), kernel=wdpm_amd.KERNEL_FUSED, thres=5e-6)
+    _compare_with_oracle(hip, oracle, "drain", R, C, seed=R + C + 1, iters=(2, 3), kernel=wdpm_amd.KERNEL_FUSED, thres=5e-6)
+    os.environ["WDPM_TILES"] = "0"
+    try:
+        _compare_with_oracle(hip, oracle, "add", R, C, seed=R + C + 2, iters=(3,), kernel=wdpm_amd.KERNEL_FUSED)
+    finally:
+        del os.environ["WDPM_TILES"]
+
+
 def test_every_width_around_strip_boundaries(hip, oracle):
     """every raster width from 165 to 200, 335 to 350 and 505 to 520 columns (a strip stores 171 columns and loads 192: widths
     that end a strip exactly, one short, one over, inside the halo ...), marching kernel (12-row chunks) and triangle kernel"""

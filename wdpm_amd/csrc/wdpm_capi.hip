@@ -238,6 +238,7 @@ int wdpm_create(wdpm_ctx **out, const wdpm_params *p) {
   x->tile_cap = x->tile_nstrips = x->tile_H = x->tile_nchunks = 0;
   x->d_active = nullptr; x->h_active = nullptr;
   x->tiles_launched = 0; x->sparse = false; x->stat_tiles = x->stat_active = 0;
+  x->wide_tri_ok = false; x->blocks_unprobed = 0;
   { const char *e = getenv("WDPM_TILES"); x->tiles_mode = e ? atoi(e) : 1; }
   x->flush_pending = false;
   x->d_md = nullptr; x->md_hint = x->md_valid = false; x->md_lo = x->md_hi = 0;
@@ -724,7 +725,7 @@ int wdpm_iterate(wdpm_ctx *x, int32_t n_iter) {
       if (x->flush_pending && x->signed_zero_safe && ensure_flushed(x)) return 1;   /* no flush-on-load variant of that kernel */
       const int t = free_slot(x);
       TilePlan tp{x->d_zero[x->cur], x->d_zero[t], x->zero_valid[x->cur] ? 1 : 0, x->zero_valid[t] ? 1 : 0, x->d_active,
-                  x->tile_cap, x->tile_nstrips, x->tile_H, x->tile_nchunks, 0};
+                  x->tile_cap, x->tile_nstrips, x->tile_H, x->tile_nchunks, 0, x->wide_tri_ok ? 1 : 0};
       const bool track = x->tiles_mode != 0 && !x->signed_zero_safe;
       /* sparse rasters march short chunks: the launch takes as long as its wettest tile */
       const int chunk_rows = x->p.chunk_rows >= 3 ? x->p.chunk_rows : (track && x->sparse ? kSparseChunkRows : 0);
@@ -874,6 +875,12 @@ int wdpm_max_diff(wdpm_ctx *x, int32_t row_lo, int32_t row_hi, double *out) {
     x->tiles_launched = 0;
     if (!x->sparse && frac < 0.30 && x->g.rows >= 4 * kSparseChunkRows) x->sparse = true;
     else if (x->sparse && frac > 0.60) x->sparse = false;
+    /* mostly wet: a raster of a few rounds of triangle waves goes to that kernel from the next block on (no flags there, so
+     * the marching kernel looks again every 16 blocks) */
+    x->wide_tri_ok = !x->sparse && frac > 0.60;
+    x->blocks_unprobed = 0;
+  } else if (x->wide_tri_ok && ++x->blocks_unprobed >= 16) {
+    x->wide_tri_ok = false;
   }
   return 0;
 }

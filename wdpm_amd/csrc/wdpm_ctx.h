@@ -35,6 +35,9 @@ struct wdpm_ctx {
   unsigned *h_active;           /* pinned */
   int64_t tiles_launched;       /* tiles of the flag-maintaining launches since the last look */
   bool sparse;                  /* most tiles are dry: short chunks (96 rows), so that a wet tile is a short march */
+  bool wide_tri_ok;             /* the last block that kept tile flags found > 60 % of the tiles working: mid-size rasters may go to the
+                                 * triangle kernel (no flags); probed again with the marching kernel every 16 blocks */
+  int blocks_unprobed;
   int tiles_mode;               /* 1 on (default), 0 off (WDPM_TILES=0 / WDPM_OPT_TILES) */
   int64_t stat_tiles, stat_active;   /* running totals for wdpm_get_option */
   /* max |w - oldw| folded into the last iteration launch of a block (wdpm_expect_max_diff) */

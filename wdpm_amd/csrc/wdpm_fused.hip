@@ -1000,7 +1000,15 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
     int nch = (out_last - A0 - 1 + 2) / 3;
     if (nch < 1) nch = 1;
     const long long items = (long long)nstr * nch;
-    if (env_tri && !signed_zero_safe && !fold_md && chunk_rows < 3 && (items <= tri_slots || env_tri == 2)) {
+    // ... and somewhat beyond: up to 2.2 rounds of triangle waves (2.7 for drain) still beat the marching kernel, whose chunks
+    // are only a few steps high at these sizes (1200^2: 24.4 -> 14.9 us per add iteration, 1800^2: 32.9 -> 32.2; drain 1200^2:
+    // 31.3 -> 20.8, 2000^2: 48.6 -> 46.8; profiles/r02/tri_sweep.txt)
+    // ... unless dry-tile flags are being kept and have not (yet, or lately) said that most of the raster works: the triangle
+    // kernel keeps no flags, and a mostly dry raster of this size is better off with the marching kernel skipping its dry tiles
+    const bool wide = !tiles || tiles->wide_tri_ok;
+    const long long slots_now = tri_slots.load(std::memory_order_relaxed);
+    const long long tri_limit = wide ? slots_now * (module == 2 ? 27 : 22) / 10 : slots_now;
+    if (env_tri && !signed_zero_safe && !fold_md && chunk_rows < 3 && (items <= tri_limit || env_tri == 2)) {
       const dim3 tgrid(((unsigned)((items + 3) / 4) + 7) / 8 * 8), tblock(256);
 #define WDPM_TRI_LAUNCH(M, F) hipLaunchKernelGGL((tri_iteration_kernel<M, F>), tgrid, tblock, 0, s, w_in, w_out, dem, g, nstr, (int)items, A0, out_last, totaldrain, thres, module == 2 ? drain_owed : 0)
       if (module == 2) { if (flush) WDPM_TRI_LAUNCH(2, true); else WDPM_TRI_LAUNCH(2, false); }

@@ -72,6 +72,8 @@ struct TilePlan {                /* host side of it, kept by the context per lau
   int capacity;                  /* in: tiles each flag array has room for */
   int nstrips, H, nchunks;       /* in: the tiling the flags were made for; out: the tiling of this launch */
   int maintained;                /* out: this launch read / wrote the flags (marching kernel, whole slab, H >= 6) */
+  int wide_tri_ok;               /* in: the last block with flags found most tiles working: the triangle kernel (which keeps no
+                                  * flags) may also take rasters of a few rounds of its waves (wdpm_launch_fused_rows) */
 };
 
 /* max |w - oldw| folded into an iteration launch (the last one of a block): the waves have the final values in
