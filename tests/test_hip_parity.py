@@ -393,7 +393,8 @@ def test_degenerate_shapes(hip, oracle, R, C):
 @pytest.mark.parametrize("R,C", [(1250, 1300), (1700, 950), (700, 2900)])
 def test_triangle_kernel_in_several_rounds(hip, oracle, R, C):
     """rasters whose 3-row chunks no longer fit on the chip at once but which the launcher still gives to the triangle kernel
-    (up to 2.2 rounds of waves, 2.7 for drain): 3 300 - 6 600 work items here, against the oracle, flush and max change included"""
+    (up to 2.7 rounds of three-row waves; add / subtract then take six rows per wave, K = 2): 3 300 - 6 600 work items here,
+    against the oracle, flush and max change included"""
     # the first block runs on the marching kernel (it keeps the dry-tile flags and so finds out that the raster is mostly wet),
     # the blocks after it on the triangle kernel; with tile tracking off the triangle kernel runs from the first launch
     _compare_with_oracle(hip, oracle, "add", R, C, seed=R + C, iters=(2, 2, 1), kernel=wdpm_amd.KERNEL_FUSED, thres=5e-6)

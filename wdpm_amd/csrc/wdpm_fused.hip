@@ -703,11 +703,16 @@ __device__ __forceinline__ void stage_lockstep(double (&W)[NR][3], const double 
     }
 }
 
-template <int MODULE, bool FLUSH>
+template <int MODULE, bool FLUSH, int K = 1>
 __global__ void __launch_bounds__(256, 2)
 tri_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout, const double *__restrict__ dem,
                      const SlabGeom g, const int nstrips, const int nitems, const int A0, const int out_last,
                      double *__restrict__ totaldrain, const double thres, const int drain_owed) {
+  // K row blocks out per wave: 3K + 6 rows in, oi = 1 on K + 2 row blocks, oi = 2 on K + 1, oi = 3 on K.  K = 1 is the kernel
+  // described above; K = 2 (add / subtract only) does 9 block stages for six rows instead of 12 - for rasters whose waves no
+  // longer fit on the chip in one round, where the launch is bound by instruction issue, not by a single wave's latency.
+  static_assert(K == 1 || MODULE != 2, "the outlet's permutation below is written for K = 1");
+  constexpr int NR = 3 * K + 6;
   const int lane = threadIdx.x & 63;
   const int vb = (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8;       // XCD-contiguous items
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -718,9 +723,9 @@ tri_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout, 
   const int oc_lo = strip == 0 ? 0 : c0 + kHaloL;
   int oc_hi = c0 + kStripIn - 1 - kHaloR;
   if (oc_hi > g.ncp - 1) oc_hi = g.ncp - 1;
-  const int A = A0 + 3 * chunk;                   // window rows A .. A+8; exact output rows A+2 .. A+4
+  const int A = A0 + 3 * K * chunk;               // window rows A .. A+NR-1; exact output rows A+2 .. A+3K+1
   const int or_lo = A == 0 ? 0 : A + 2;
-  int or_hi = A + 4;
+  int or_hi = A + 3 * K + 1;
   if (or_hi > out_last) or_hi = out_last;
   const int colb = c0 + 3 * lane;
   const size_t pitch = (size_t)g.ncp;
@@ -749,13 +754,13 @@ tri_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout, 
   // nine rows x three columns per lane; cells outside the slab: dem = +inf, water = 0.  Row bases are
   // wave-uniform (scalar registers), the lane contributes a 32-bit byte offset: saddr-form loads, no 64-bit
   // address arithmetic on the vector unit.  Only waves at the slab's right / lower edge mask anything.
-  const bool edge = (c0 + kStripIn > g.ncp) || (A + 9 > g.rows);                   // wave-uniform
+  const bool edge = (c0 + kStripIn > g.ncp) || (A + NR > g.rows);                  // wave-uniform
   unsigned voff[3];
 #pragma unroll
   for (int j = 0; j < 3; j++) voff[j] = 8u * (unsigned)(colb + j < g.ncp ? colb + j : g.ncp - 1);
-  double W[9][3], D[9][3];
+  double W[NR][3], D[NR][3];
 #pragma unroll
-  for (int i = 0; i < 9; i++) {
+  for (int i = 0; i < NR; i++) {
     const int rc = A + i < g.rows ? A + i : g.rows - 1;
     const char *bw = reinterpret_cast<const char *>(win + (size_t)rc * pitch);
     const char *bd = reinterpret_cast<const char *>(dem + (size_t)rc * pitch);
@@ -767,13 +772,13 @@ tri_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout, 
   }
   if (FLUSH) {
 #pragma unroll
-    for (int i = 0; i < 9; i++)
+    for (int i = 0; i < NR; i++)
 #pragma unroll
       for (int j = 0; j < 3; j++) W[i][j] = W[i][j] < thres ? 0.0 : W[i][j];       // WDPMCL.c:1059-1062
   }
-  if (MODULE == 2 && drain_owed && outlet_inside && A + 8 >= g.dr - 1 && A <= g.dr + 1) {   // wave-uniform, rare
+  if (MODULE == 2 && drain_owed && outlet_inside && A + NR - 1 >= g.dr - 1 && A <= g.dr + 1) {   // wave-uniform, rare
 #pragma unroll
-    for (int i = 0; i < 9; i++)
+    for (int i = 0; i < NR; i++)
 #pragma unroll
       for (int j = 0; j < 3; j++) {
         const int r = A + i, c = colb + j;
@@ -782,7 +787,7 @@ tri_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout, 
   }
   if (edge) {
 #pragma unroll
-    for (int i = 0; i < 9; i++)
+    for (int i = 0; i < NR; i++)
 #pragma unroll
       for (int j = 0; j < 3; j++) {
         const bool ok = (A + i < g.rows) & (colb + j < g.ncp);
@@ -791,7 +796,9 @@ tri_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout, 
       }
   }
 
-  if (MODULE == 2 && g.dr >= A && g.dr <= A + 8) {
+  bool outlet_here = false;
+  if constexpr (MODULE == 2) outlet_here = g.dr >= A && g.dr <= A + 8;
+  if constexpr (MODULE == 2) if (outlet_here) {
     // The outlet's row is in this window (a handful of waves).  In every row alignment at most ONE row block
     // holds that row (row blocks of an alignment are disjoint, so totaldrain still accumulates in pass order):
     // it runs the marching kernel's stage with runoffd()'s sink, the other blocks of the alignment stay in
@@ -870,15 +877,16 @@ tri_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout, 
     } else {
       stage_lockstep<2, 1, 2, 9>(W, D);
     }
-  } else {
-    stage_lockstep<MODULE, 3, 0, 9>(W, D);        // oi = 1 on rows 0-2, 3-5, 6-8
-    stage_lockstep<MODULE, 2, 1, 9>(W, D);        // oi = 2 on rows 1-3, 4-6
-    stage_lockstep<MODULE, 1, 2, 9>(W, D);        // oi = 3 on rows 2-4
+  }
+  if (!outlet_here) {
+    stage_lockstep<MODULE, K + 2, 0, NR>(W, D);   // oi = 1 on rows 0-2, 3-5, 6-8 (, 9-11)
+    stage_lockstep<MODULE, K + 1, 1, NR>(W, D);   // oi = 2 on rows 1-3, 4-6 (, 7-9)
+    stage_lockstep<MODULE, K, 2, NR>(W, D);       // oi = 3 on rows 2-4 (, 5-7)
   }
 
   // rows or_lo .. or_hi, columns oc_lo .. oc_hi (slots 0 and 1 only for the raster's first rows)
 #pragma unroll
-  for (int i = 0; i < 5; i++) {
+  for (int i = 0; i < 3 * K + 2; i++) {
     const int r = A + i;
     if (r < or_lo || r > or_hi) continue;                                    // wave-uniform
 #pragma unroll
@@ -999,19 +1007,31 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
     if (g.ncp > kStripIn - kHaloR) nstr = (g.ncp - (kStripIn - kHaloR) + kStripOut - 1) / kStripOut + 1;
     int nch = (out_last - A0 - 1 + 2) / 3;
     if (nch < 1) nch = 1;
-    const long long items = (long long)nstr * nch;
-    // ... and somewhat beyond: up to 2.2 rounds of triangle waves (2.7 for drain) still beat the marching kernel, whose chunks
-    // are only a few steps high at these sizes (1200^2: 24.4 -> 14.9 us per add iteration, 1800^2: 32.9 -> 32.2; drain 1200^2:
-    // 31.3 -> 20.8, 2000^2: 48.6 -> 46.8; profiles/r02/tri_sweep.txt)
+    long long items = (long long)nstr * nch;
+    static std::atomic<int> env_k{-1};      // WDPM_TRI_K=1|2 forces the triangle kernel's height (tuning, tests); 0 = automatic
+    if (env_k < 0) { const char *t = getenv("WDPM_TRI_K"); env_k = t ? atoi(t) : 0; }
+    // ... and somewhat beyond: up to 2.7 rounds of (three-row) triangle waves still beat the marching kernel, whose chunks are
+    // only a few steps high at these sizes - with six rows per wave (K = 2) for add / subtract once there is more than one round
+    // (1200^2: 24.5 -> 14.7 us per add iteration, 1600^2: 30.2 -> 24.6, 2000^2: 35.8 -> 33.7; drain 1200^2: 31.3 -> 20.8,
+    // 2000^2: 48.6 -> 46.8; profiles/r02/tri_sweep.txt)
     // ... unless dry-tile flags are being kept and have not (yet, or lately) said that most of the raster works: the triangle
     // kernel keeps no flags, and a mostly dry raster of this size is better off with the marching kernel skipping its dry tiles
     const bool wide = !tiles || tiles->wide_tri_ok;
     const long long slots_now = tri_slots.load(std::memory_order_relaxed);
-    const long long tri_limit = wide ? slots_now * (module == 2 ? 27 : 22) / 10 : slots_now;
+    const long long tri_limit = wide ? slots_now * 27 / 10 : slots_now;
     if (env_tri && !signed_zero_safe && !fold_md && chunk_rows < 3 && (items <= tri_limit || env_tri == 2)) {
+      // more than one round of waves: the launch is bound by instruction issue, and six rows per wave (K = 2: 9 block stages
+      // instead of 12 for them) are the cheaper way through; one round: three rows per wave is the shorter critical path
+      const bool two = module != 2 && (env_k == 2 || (env_k == 0 && items > slots_now));
+      if (two) {
+        nch = (out_last - A0 - 1 + 5) / 6;
+        if (nch < 1) nch = 1;
+        items = (long long)nstr * nch;
+      }
       const dim3 tgrid(((unsigned)((items + 3) / 4) + 7) / 8 * 8), tblock(256);
-#define WDPM_TRI_LAUNCH(M, F) hipLaunchKernelGGL((tri_iteration_kernel<M, F>), tgrid, tblock, 0, s, w_in, w_out, dem, g, nstr, (int)items, A0, out_last, totaldrain, thres, module == 2 ? drain_owed : 0)
+#define WDPM_TRI_LAUNCH(...) hipLaunchKernelGGL((tri_iteration_kernel<__VA_ARGS__>), tgrid, tblock, 0, s, w_in, w_out, dem, g, nstr, (int)items, A0, out_last, totaldrain, thres, module == 2 ? drain_owed : 0)
       if (module == 2) { if (flush) WDPM_TRI_LAUNCH(2, true); else WDPM_TRI_LAUNCH(2, false); }
+      else if (two) { if (flush) WDPM_TRI_LAUNCH(0, true, 2); else WDPM_TRI_LAUNCH(0, false, 2); }
       else { if (flush) WDPM_TRI_LAUNCH(0, true); else WDPM_TRI_LAUNCH(0, false); }
 #undef WDPM_TRI_LAUNCH
       return hipGetLastError();
