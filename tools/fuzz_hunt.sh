@@ -5,3 +5,7 @@ for t in "tests/test_hip_parity.py -k random_call" "tests/test_dry_tiles.py -k r
   echo "== $t seeds $lo:$hi"; WDPM_FUZZ_SEEDS=$lo:$hi timeout -k 10 900 python -m pytest $t -m gpu -q -x 2>&1 | tail -n 6
 done
 echo "== CLI differential seeds $lo:$((lo + 400))"; WDPM_FUZZ_SEEDS=$lo:$((lo + 400)) timeout -k 10 900 python -m pytest tests/test_cli_differential.py -m gpu -q -x 2>&1 | tail -n 6
+echo "== the same call sequences and row-block jobs with six rows per triangle wave forced (WDPM_TRI_K=2)"
+for t in "tests/test_hip_parity.py -k random_call" "tests/test_rowblock.py -k hip_random_group" "tests/test_hip_parity.py -k every_"; do
+  WDPM_TRI_K=2 WDPM_FUZZ_SEEDS=$lo:$hi timeout -k 10 900 python -m pytest $t -m gpu -q -x 2>&1 | tail -n 3
+done
