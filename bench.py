@@ -15,8 +15,16 @@ Rank 0 prints ONE JSON line.
 (`python -m torch.distributed.run ...` of this same file, before anything here has touched the GPU),
 relays rank 0's line and exits with the launcher's status.  `--driver group` instead runs all N ranks
 inside THIS process, one host thread per GPU (wdpm_group_*: what the WDPMCL drop-in does with
-WDPM_GPUS=N).  On a box with fewer GPUs than ranks (rehearsal) the ranks share GPUs, torch.distributed
-runs on gloo and the halos are staged through the host (RCCL wants one GPU per rank); the line says so.
+WDPM_GPUS=N).  On a box with fewer GPUs than ranks (rehearsal) the ranks share GPUs and the halos are
+staged through the host (RCCL wants one GPU per rank); the line says so.
+
+Nothing in an N-rank run can end without a line.  torch.distributed (gloo by default: the control plane -
+barriers, the communicator id, a handful of scalars - needs no GPU fabric) only brackets the timed region;
+the halos travel by the library's own RCCL communicator, whose set-up and first transfer run with deadlines
+(WDPM_RCCL_TIMEOUT_S / WDPM_SYNC_TIMEOUT_S, include/wdpm.h).  If any rank's RCCL refuses, fails or runs past
+a deadline, ALL ranks agree on it (one all-reduce) and go on with host-staged halos over gloo in the same
+processes; the line then says `"degraded": true` and why.  The synthetic DEM is generated ONCE per node
+(local rank 0 -> /dev/shm, the others map their rows).
 """
 import argparse
 import json
@@ -36,40 +44,107 @@ ADD_M = 0.1                         # add 100 mm, runoff fraction 1.0
 MISSING = -99999.0
 
 
-def build_slab_inputs(lib, n, slab):
-    """padded dem / water rows [row0, row0+rows) of the config-4 workload"""
-    dem = lib.synth_dem(n, n)                      # integer-seeded generator, seed = size
-    ncp = n + 2
-    bd = np.full((slab.rows, ncp), MISSING)
-    lo, hi = max(slab.row0, 1), min(slab.row0 + slab.rows, n + 1)   # padded interior rows held
-    bd[lo - slab.row0:hi - slab.row0, 1:-1] = dem[lo - 1:hi - 1]
-    del dem
-    bw = np.where(bd > MISSING, ADD_M, 0.0)
-    return bd, bw
+class SharedDem:
+    """The n x n synthetic DEM of the workload (integer-seeded C generator, seed = size), made ONCE per node: local rank 0
+    writes it to /dev/shm, everybody else maps it read-only after a barrier (round 2: every rank generated the whole raster
+    to keep its eighth - 2.1 GB and 4-27 s of one core per rank at 16384^2).  Falls back to generating it in this process
+    when there is nothing to share with (one rank) or /dev/shm cannot be used."""
+
+    def __init__(self, lib, n, dist, local_rank):
+        self.n, self.path, self.owner, self.dist = n, None, False, dist
+        if dist is None:
+            self.dem = lib.synth_dem(n, n)
+            return
+        run = os.environ.get("TORCHELASTIC_RUN_ID", "") + "_" + os.environ.get("MASTER_PORT", "0")
+        path = f"/dev/shm/wdpm_bench_{os.getuid()}_{''.join(c for c in run if c.isalnum() or c == '_')}_{n}.npy"
+        ok = 1.0
+        if local_rank == 0:
+            try:
+                m = np.lib.format.open_memmap(path, mode="w+", dtype=np.float64, shape=(n, n))
+                lib.check(lib.dll.wdpm_synth_dem(n, n, m.ctypes.data))
+                m.flush()
+                del m
+                self.owner = True
+            except Exception as e:  # noqa: BLE001 - no /dev/shm, no room: every rank makes its own
+                print(f"bench.py: cannot share the DEM through {path} ({e}); every rank generates it", file=sys.stderr)
+                ok = 0.0
+        import torch
+        t = torch.tensor([ok], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)        # also the barrier behind which the file is complete
+        if t.item() > 0:
+            self.path = path
+            self.dem = np.load(path, mmap_mode="r")
+        else:
+            self.dem = lib.synth_dem(n, n)
+
+    def slab_inputs(self, slab):
+        """padded dem / water rows [row0, row0+rows) of the config-4 workload"""
+        n, ncp = self.n, self.n + 2
+        bd = np.full((slab.rows, ncp), MISSING)
+        lo, hi = max(slab.row0, 1), min(slab.row0 + slab.rows, n + 1)   # padded interior rows held
+        bd[lo - slab.row0:hi - slab.row0, 1:-1] = self.dem[lo - 1:hi - 1]
+        bw = np.where(bd > MISSING, ADD_M, 0.0)
+        return bd, bw
+
+    def whole_inputs(self):
+        n = self.n
+        bd = np.full((n + 2, n + 2), MISSING)
+        bd[1:-1, 1:-1] = self.dem
+        return bd, np.where(bd > MISSING, ADD_M, 0.0)
+
+    def argmin(self):
+        return int(np.argmin(self.dem))
+
+    def close(self):
+        """collective: nobody needs the file any more"""
+        self.dem = None
+        if self.dist is not None:
+            self.dist.barrier()
+        if self.owner and self.path:
+            try:
+                os.unlink(self.path)
+            except OSError:
+                pass
 
 
-def measured_traffic(n, world, kernel, dem32):
-    """HBM bytes per fused-kernel launch from the committed rocprofv3 PMC passes (separate
-    --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command, gfx950 x2 FETCH correction,
-    calibrated on kernels of known byte count: profiles/).  Only for the configuration they
-    were taken on; otherwise null.  With the DEM streamed as 32-bit codes the kernel moves 20 B per
-    cell-update, i.e. LESS than the 24 algorithmic bytes `achieved` is priced at."""
+def measured_counters(n, world, kernel, dem32):
+    """Counter evidence for the dominant kernel from the committed rocprofv3 PMC passes (separate
+    --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE runs of this same command,
+    gfx950 x2 FETCH correction, calibrated on kernels of known byte count: profiles/).  Only for the
+    configuration they were taken on; otherwise {}.  With the DEM streamed as 32-bit codes the kernel
+    moves 20 B per cell-update, i.e. LESS than the 24 algorithmic bytes `achieved` is priced at.
+    -> dict(traffic=HBM bytes per launch, valu_issue_frac=share of the kernel's cycles in which a SIMD issues a VALU
+    instruction (SQ_INSTS_VALU x 4 cycles / SIMDs / (GRBM_GUI_ACTIVE / XCDs)), source=...)"""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
             t = json.load(f)
         if t["size"] == n and t["n_gpus"] == world and kernel in ("auto", "fused"):
-            return t["dem32" if dem32 else "fp64_dem"]["hbm_bytes_per_launch"]
+            e = t["dem32" if dem32 else "fp64_dem"]
+            return {"traffic": e["hbm_bytes_per_launch"], "valu_issue_frac": e.get("valu_issue_frac"),
+                    "kernel_ms_at_collection": e.get("kernel_ms"), "source": e.get("source")}
     except (OSError, KeyError, ValueError):
         pass
-    return None
+    return {}
 
 
-def reference_baseline(n, iters):
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def reference_baseline(samples):
     """The UNMODIFIED reference's serial functions (runoffs() on its own double** globals, driven in
     the loop order of WDPMCL.c:1097-1103) from oracle/_ref/libwdpm_ref.so, which oracle/Makefile
     builds from the sources where they lie under /root/reference and which travels to the GPU box as
-    a binary.  None if that library is not there or does not load."""
+    a binary.  samples = [(n, iterations), ...] -> list of results, or None if that library is not
+    there or does not load."""
     import ctypes as C
     import wdpm_amd
     so = os.path.join(ROOT, "oracle", "_ref", "libwdpm_ref.so")
@@ -79,61 +154,89 @@ def reference_baseline(n, iters):
         ref.ref_iterate.argtypes = [C.c_int, C.c_int]
     except (OSError, AttributeError):
         return None
-    dem = wdpm_amd.load_hip().synth_dem(n, n)
-    bd = np.full((n + 2, n + 2), MISSING)
-    bd[1:-1, 1:-1] = dem
-    bw = np.where(bd > MISSING, ADD_M, 0.0)
-    ref.ref_setup(n, n, MISSING, bd.ctypes.data, bw.ctypes.data, 0.0, 0, 0)
-    ref.ref_iterate(0, 1)
-    t = time.perf_counter()
-    ref.ref_iterate(0, iters)
-    dt = time.perf_counter() - t
-    return {"value": n * n * iters / dt, "unit": "cell-updates/s", "cores": 1, "kind": "reference",
-            "sample": f"runoffs() of the unmodified src/WDPMCL.c (oracle/_ref/libwdpm_ref.so), synthetic {n}x{n} "
-                      f"all-wet add 100 mm, {iters} iterations, {dt:.1f} s"}
+    out = []
+    for n, iters in samples:
+        dem = wdpm_amd.load_hip().synth_dem(n, n)
+        bd = np.full((n + 2, n + 2), MISSING)
+        bd[1:-1, 1:-1] = dem
+        del dem
+        bw = np.where(bd > MISSING, ADD_M, 0.0)
+        ref.ref_setup(n, n, MISSING, bd.ctypes.data, bw.ctypes.data, 0.0, 0, 0)
+        del bd, bw
+        ref.ref_iterate(0, 1)
+        t = time.perf_counter()
+        ref.ref_iterate(0, iters)
+        dt = time.perf_counter() - t
+        out.append({"size": n, "iterations": iters, "seconds": round(dt, 2), "value": n * n * iters / dt})
+    return out
 
 
-def cpu_baseline(n=4096, iters=32):
-    """The reference's own serial code if its prebuilt library is present (kind "reference"), else the
-    CPU oracle (bit-equal port of it, kind "port"), timed on one host core on a bounded sample of the
-    same workload.  A reported baseline, never the product path."""
+def oracle_baseline(samples):
+    """the CPU oracle (bit-equal port of the reference's serial path) on the same samples"""
     import subprocess
     import wdpm_amd
-    ref = reference_baseline(n, 24)
-    if ref is not None:
-        return ref
     so = os.path.join(ROOT, "oracle", "_build", "libwdpm_oracle.so")
     if not os.path.exists(so):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "oracle"], stdout=subprocess.DEVNULL)
     orc = wdpm_amd.load(so)
-    dem = orc.synth_dem(n, n)
-    bd = np.full((n + 2, n + 2), MISSING)
-    bd[1:-1, 1:-1] = dem
-    bw = np.where(bd > MISSING, ADD_M, 0.0)
-    with orc.context(module="add", nrows=n, ncols=n, missingvalue=MISSING) as c:
-        c.upload(bd, bw)
-        c.iterate(1)
-        t = time.perf_counter()
-        c.run_block(iters, THRES)
-        dt = time.perf_counter() - t
-    return {"value": n * n * iters / dt, "unit": "cell-updates/s", "cores": 1, "kind": "port",
-            "sample": f"oracle/wdpm_oracle.c, synthetic {n}x{n} all-wet add 100 mm, {iters} iterations, {dt:.1f} s"}
+    out = []
+    for n, iters in samples:
+        dem = orc.synth_dem(n, n)
+        bd = np.full((n + 2, n + 2), MISSING)
+        bd[1:-1, 1:-1] = dem
+        bw = np.where(bd > MISSING, ADD_M, 0.0)
+        with orc.context(module="add", nrows=n, ncols=n, missingvalue=MISSING) as c:
+            c.upload(bd, bw)
+            c.iterate(1)
+            t = time.perf_counter()
+            c.run_block(iters, THRES)
+            dt = time.perf_counter() - t
+        out.append({"size": n, "iterations": iters, "seconds": round(dt, 2), "value": n * n * iters / dt})
+    return out
+
+
+def cpu_baseline(full=False):
+    """The reference's own serial code if its prebuilt library is present (kind "reference"), else the
+    CPU oracle (bit-equal port of it, kind "port"), timed on ONE host core (the reference's serial path is
+    single-threaded) on bounded samples of the same workload: SURVEY.md §8d's 1024^2 x 1000 iterations
+    (cache-resident) and 4096^2 x 24 (memory-resident, as the 16384^2 workload is: the headline `value`);
+    `--cpu-baseline-full` adds §8d's 16384^2 x 10 (about a minute) and makes it the headline.
+    A reported baseline, never the product path."""
+    samples = [(4096, 24), (1024, 1000)] + ([(16384, 10)] if full else [])
+    kind, res = "reference", reference_baseline(samples)
+    if res is None:
+        kind, res = "port", oracle_baseline(samples)
+    head = res[-1] if full else res[0]
+    what = ("runoffs() of the unmodified src/WDPMCL.c (oracle/_ref/libwdpm_ref.so)" if kind == "reference" else
+            "oracle/wdpm_oracle.c")
+    return {"value": head["value"], "unit": "cell-updates/s", "cores": 1, "kind": kind, "cpu_model": cpu_model(),
+            "host_cores": os.cpu_count(),
+            "sample": f"{what}, synthetic {head['size']}x{head['size']} all-wet add 100 mm, {head['iterations']} iterations, "
+                      f"{head['seconds']:.1f} s, one thread (the reference's serial path has no other)",
+            "samples": res}
 
 
 def self_launch(args):
     """`python bench.py --gpus N` with no launcher: start the N ranks as CHILD processes (never exec: this
     process has not touched the GPU and will not), relay rank 0's JSON line, return the launcher's status.
-    If the ranks fail or hang with GPU-direct halos (RCCL communicator set-up is the one step of this path that
-    can block for ever on a node whose fabric or IPC is misconfigured), they are started once more with
-    host-staged halos over gloo; the JSON line says which transport ran (`config.halo`, `config.dist_backend`)."""
+    The ranks settle a refused or stuck RCCL among themselves (host-staged halos in the same processes, see main()); what
+    is left for this level is a run that crashes or does not finish at all: it is started ONCE more with host-staged
+    halos from the outset, within what is left of the time budget (WDPM_BENCH_BUDGET_S, default 560 s: under the driver's
+    600 s), and the line of that second run carries `"degraded": true` and the first attempt's status, so that it cannot
+    be mistaken for a GPU-direct result."""
     import signal
     import socket
     import subprocess
+    t_start = time.monotonic()
+    budget = float(os.environ.get("WDPM_BENCH_BUDGET_S", "560"))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}"]
-    limit = float(os.environ.get("WDPM_BENCH_RANKS_TIMEOUT", "900"))
+    first_limit = min(float(os.environ.get("WDPM_BENCH_RANKS_TIMEOUT", "200")), budget)
 
-    def launch(rdzv, env):
+    def elapsed():
+        return time.monotonic() - t_start
+
+    def launch(rdzv, env, limit):
         """-> (return code or None on timeout, stdout, stderr); the children get their own process group so that a
         hung run can be ended as a whole (by that exact group id, nothing else)"""
         p = subprocess.Popen(base + rdzv + [os.path.abspath(__file__), *sys.argv[1:]], stdout=subprocess.PIPE,
@@ -149,7 +252,8 @@ def self_launch(args):
             out, err = p.communicate()
             return None, out, err
 
-    def run(env):
+    def run(env, limit):
+        t_end = time.monotonic() + limit
         for attempt in range(3):
             if attempt == 0:       # the launcher picks and holds its own rendezvous port
                 rdzv = ["--standalone", "--local-addr", "127.0.0.1"]
@@ -157,25 +261,39 @@ def self_launch(args):
                 with socket.socket() as s:
                     s.bind(("127.0.0.1", 0))
                     rdzv = ["--master-addr", "127.0.0.1", "--master-port", str(s.getsockname()[1])]
-            rc, out, err = launch(rdzv, env)
+            rc, out, err = launch(rdzv, env, max(t_end - time.monotonic(), 1.0))
             sys.stderr.write(err)
             if rc == 0 or rc is None or "EADDRINUSE" not in err:
                 break              # only a lost race for the rendezvous port is worth another try
         return rc, out
 
-    rc, out = run(env)
+    rc, out = run(env, first_limit)
     lines = [ln for ln in out.splitlines() if ln.startswith('{"metric"')]
-    gpu_direct = env.get("WDPM_HALO", "rccl") == "rccl" and env.get("WDPM_DIST_BACKEND", "nccl") == "nccl"
+    gpu_direct = env.get("WDPM_HALO", "rccl") == "rccl"
+    first = None
     if (rc != 0 or not lines) and gpu_direct:
-        print(f"bench.py: the ranks {'did not finish within %.0f s' % limit if rc is None else 'ended with status %d' % rc} "
-              f"on RCCL halos; starting them again with host-staged halos over gloo", file=sys.stderr, flush=True)
-        rc, out = run(dict(env, WDPM_HALO="host", WDPM_DIST_BACKEND="gloo"))
-        lines = [ln for ln in out.splitlines() if ln.startswith('{"metric"')]
+        first = f"no result within {first_limit:.0f} s" if rc is None else f"exit status {rc}"
+        left = budget - elapsed() - 5.0
+        print(f"bench.py: the ranks ended with {first} after {elapsed():.0f} s of a {budget:.0f} s budget; "
+              f"starting them once more with host-staged halos over gloo ({left:.0f} s left)", file=sys.stderr, flush=True)
+        if left > 20.0:
+            rc, out = run(dict(env, WDPM_HALO="host", WDPM_DIST_BACKEND="gloo"), left)
+            lines = [ln for ln in out.splitlines() if ln.startswith('{"metric"')]
     for ln in out.splitlines():
         if not ln.startswith('{"metric"'):
             print(ln, file=sys.stderr)
     if lines:
-        print(lines[-1], flush=True)
+        line = lines[-1]
+        if first is not None:      # the second attempt's line: say what it is
+            try:
+                d = json.loads(line)
+                d["degraded"] = True
+                d["first_attempt"] = f"{first} on RCCL halos; this line is a second run with host-staged halos"
+                line = json.dumps(d)
+            except ValueError:
+                pass
+        print(line, flush=True)
+    print(f"bench.py: {elapsed():.0f} s of the {budget:.0f} s budget used", file=sys.stderr, flush=True)
     if rc is None:
         return 124
     return rc if rc != 0 or lines else 1
@@ -196,6 +314,8 @@ def main():
                     help="drain = BASELINE config 5: water-in is the add-100-mm state after --drain-spinup iterations")
     ap.add_argument("--drain-spinup", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-full", action="store_true",
+                    help="also time SURVEY §8d's 16384^2 x 10 iterations on the host (about a minute) and make it the headline")
     args = ap.parse_args()
 
     launched = "WORLD_SIZE" in os.environ
@@ -205,6 +325,11 @@ def main():
     # multi-process GPU work on this driver needs dmabuf IPC (RCCL, tensors shared across processes); exported on the pool's
     # boxes already - set here too, before the runtime is loaded, for a shell that lacks it
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # the library's deadlines for communicator set-up / the first transfer and for stream waits: tighter than its defaults,
+    # so that a stuck fabric costs the bench a minute, not its whole time budget
+    os.environ.setdefault("WDPM_RCCL_TIMEOUT_S", "60")
+    os.environ.setdefault("WDPM_SYNC_TIMEOUT_S", "120")
+    t_proc = time.monotonic()
     import torch
     import wdpm_amd
     from wdpm_amd.rowblock import Group, HostTransport, RowBlockSolver
@@ -217,9 +342,12 @@ def main():
     ngpu = torch.cuda.device_count()
     if ngpu < 1 or not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    # fewer GPUs than ranks (rehearsal on a one-GPU box): ranks share GPUs, which RCCL refuses - gloo + host halos
+    # fewer GPUs than ranks (rehearsal on a one-GPU box): ranks share GPUs, which RCCL refuses - host halos
     shared = ngpu < args.gpus
-    backend = os.environ.get("WDPM_DIST_BACKEND", "gloo" if shared else "nccl")
+    # The control plane (barriers around the timed region, the communicator id, a few scalars) runs on gloo: it needs no
+    # GPU fabric, so a node whose RCCL is in trouble still gets as far as finding that out - and past it.  The halos go
+    # through the library's own RCCL communicator.  WDPM_DIST_BACKEND=nccl puts the control plane on RCCL too.
+    backend = os.environ.get("WDPM_DIST_BACKEND", "gloo")
     halo = os.environ.get("WDPM_HALO", "host" if shared else "rccl")
     device = local_rank % ngpu
     torch.cuda.set_device(device)
@@ -234,41 +362,32 @@ def main():
     lib = wdpm_amd.load_hip()
     n = args.size
     kernel = {"auto": wdpm_amd.KERNEL_AUTO, "pass": wdpm_amd.KERNEL_PASS, "fused": wdpm_amd.KERNEL_FUSED}[args.kernel]
+    shared_dem = SharedDem(lib, n, dist, local_rank)
     drain_kw = {}
     if args.module == "drain":
         # the outlet is the first row-major minimum of the DEM (WDPMCL.c:1005-1017), padded coordinates
-        full = lib.synth_dem(n, n)
-        k = int(np.argmin(full))
+        k = shared_dem.argmin()
         drain_kw = dict(drainrow=k // n + 1, draincol=k % n + 1)
-        del full
 
-    def dist_max(v):
+    def dist_reduce(v, op):
         if world == 1:
             return v
         t = torch.tensor([v], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=op)
         return float(t.item())
 
-    def sync():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    def whole_inputs():
-        dem = lib.synth_dem(n, n)
-        bd = np.full((n + 2, n + 2), MISSING)
-        bd[1:-1, 1:-1] = dem
-        del dem
-        return bd, np.where(bd > MISSING, ADD_M, 0.0)
+    def dist_max(v):
+        return dist_reduce(v, dist.ReduceOp.MAX) if world > 1 else v
 
     stats_s = None
     rccl_ranks = None
+    degraded = None               # why the run is not the GPU-direct one that was asked for
+    k_used = args.exchange_every
     if args.driver == "group":
         # ---- all ranks in this process: wdpm_group_* (thread per GPU, RCCL via ncclCommInitAll or peer copies)
         devs = [int(d) for d in os.environ["WDPM_DEVICES"].split(",")] if os.environ.get("WDPM_DEVICES") else \
                [g % ngpu for g in range(args.gpus)]
-        bd, bw = whole_inputs()
+        bd, bw = shared_dem.whole_inputs()
         grp = Group(lib, "add", n, n, MISSING, devs, exchange_every=args.exchange_every, kernel=kernel)
         grp.upload(bd, bw)
         if args.module == "drain":
@@ -279,8 +398,13 @@ def main():
             grp.upload(bd, bw)
             grp.set_totaldrain(max(float(bw[drain_kw["drainrow"], drain_kw["draincol"]]), 0.0))
         del bd, bw
+        shared_dem.close()
         ranks_used, halo = grp.size, wdpm_amd.HALO_NAMES[grp.halo_kind]
         ctx0 = grp.rank_ctx(0)
+        import ctypes as C
+        kk = C.c_int32()
+        lib.check(lib.dll.wdpm_rank_info(lib.dll.wdpm_group_rank(grp._h, 0), None, C.byref(kk), None))
+        k_used = kk.value
         grp.run_block(args.warmup, THRES)           # untimed warm-up steps (ends with a synchronous reduction)
         e0, x0, _ = grp.enqueue_stats()
         lib.check(lib.dll.wdpm_timing_reset(ctx0))
@@ -295,7 +419,6 @@ def main():
         e1, x1, _ = grp.enqueue_stats()
         enqueue_us = (e1 - e0) / max(ranks_used, 1) / max(args.steps, 1) * 1e6
         refresh_us = (x1 - x0) / max(ranks_used, 1) / max(args.steps, 1) * 1e6
-        import ctypes as C
         la, ms = C.c_int64(), C.c_double()
         lib.check(lib.dll.wdpm_timing_get(ctx0, C.byref(la), C.byref(ms)))
         launches, kernel_ms = la.value, ms.value
@@ -325,28 +448,34 @@ def main():
 
         solver, refused = None, ""
         try:
-            solver = make_solver("add")
-            bd, bw = build_slab_inputs(lib, n, solver.slab)
+            solver = make_solver("add")                # RCCL: communicator set-up, with the library's deadline
+            bd, bw = shared_dem.slab_inputs(solver.slab)
             solver.upload(bd, bw)
             if world > 1:
-                solver.exchange()                      # the first transfer: communicator set-up, peer mappings
+                solver.exchange()                      # the first transfer: peer mappings, links - with a deadline too
                 solver.ctx.synchronize()
-        except Exception as e:  # noqa: BLE001 - a platform that refuses GPU-direct halos
+                # ... and once through everything a block does across ranks (iteration groups, the overlapped last
+                # iteration with the transfer beside it, the refresh, the all-gather of max diff), then back to the start
+                solver.run_block(2 * solver.k + 1, THRES)
+                solver.upload(bd, bw)
+        except Exception as e:  # noqa: BLE001 - a platform that refuses GPU-direct halos, or one that never answers
             refused = f"{type(e).__name__}: {e}"
         if world > 1 and halo == "rccl":
             # decided by ALL ranks together (a rank on its own must never change transport): any refusal anywhere
-            # puts every rank on host-staged halos
-            flag = torch.tensor([1.0 if refused else 0.0], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-            if flag.item() > 0:
+            # puts every rank on host-staged halos, in these same processes
+            if dist_reduce(1.0 if refused else 0.0, dist.ReduceOp.MAX) > 0:
+                why = [None] * world
+                dist.all_gather_object(why, refused)
+                why = next((w for w in why if w), "")
                 if rank == 0:
-                    print(f"bench.py: RCCL halos refused ({refused or 'on another rank'}); every rank switches to "
-                          f"host-staged halos", file=sys.stderr, flush=True)
+                    print(f"bench.py: RCCL halos are not to be had after {time.monotonic() - t_proc:.0f} s ({why}); every rank "
+                          f"switches to host-staged halos", file=sys.stderr, flush=True)
                 if solver is not None:
+                    solver.abort_comm()                # the peers' queued receives end; nothing of it is waited for
                     solver.close()
-                halo, refused = "host (RCCL refused)", ""
+                halo, refused, degraded = "host (RCCL refused)", "", f"RCCL halos refused or timed out: {why}"
                 solver = RowBlockSolver(lib, "add", n, n, MISSING, halo="host", transport=HostTransport(dist, host_group), **mk)
-                bd, bw = build_slab_inputs(lib, n, solver.slab)
+                bd, bw = shared_dem.slab_inputs(solver.slab)
                 solver.upload(bd, bw)
         if refused:
             raise SystemExit(f"bench.py: {refused}")
@@ -367,15 +496,24 @@ def main():
             w_out = float(bw[dr - s.row0, drain_kw["draincol"]]) if s.row0 <= dr < s.row0 + s.rows else 0.0
             solver.set_totaldrain(max(dist_max(w_out), 0.0))
         del bd, bw
+        shared_dem.close()
         ranks_used = world
         rccl_ranks = solver.rccl_ranks()
+        k_used = solver.k
+        if world > 1 and k_used != args.exchange_every and rank == 0:
+            print(f"bench.py: exchange interval {args.exchange_every} does not fit these slabs; the library uses {k_used}",
+                  file=sys.stderr, flush=True)
         solver.run_block(args.warmup, THRES)           # untimed warm-up steps
         if world > 1:
             solver.exchange()                          # the transport's first use is never timed
-        sync()
+        # the opening bracket: everybody's queue is empty, everybody is here
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
         solver.ctx.timing_reset()
         t0 = time.perf_counter()
-        max_diff = solver.run_block(args.steps, THRES) # exactly K timed steps
+        max_diff = solver.run_block(args.steps, THRES) # exactly K timed steps (ends with the ranks' all-gather of max diff)
         if args.module == "drain":
             # the drain module's per-block bookkeeping (WDPMCL.c:1257-1268) belongs to the block loop: |d totaldrain|
             # and the sequential row-major volume sum (evaluated exactly on the device; rank-chained at N > 1)
@@ -383,8 +521,14 @@ def main():
             ts = time.perf_counter()
             solver.drain_stats()
             stats_s = time.perf_counter() - ts
-        sync()
-        dt = dist_max(time.perf_counter() - t0)
+        # the closing bracket.  Each rank stops its own clock when ITS device is idle, then all meet; the job's time is
+        # the MAX over ranks (the block's last step is a collective, so no rank can be early by more than that step)
+        torch.cuda.synchronize()
+        dt_mine = time.perf_counter() - t0
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+        dt = dist_max(dt_mine)
         launches, kernel_ms = solver.ctx.timing()
         steady_launches, steady_ms = solver.ctx.timing_steady()
         dem32 = bool(solver.ctx.get_option(wdpm_amd.OPT_DEM32)) and args.module == "add"
@@ -405,7 +549,17 @@ def main():
         iter_ms = steady_ms / steady_launches if steady_launches > 0 else all_ms
         achieved = ALGO_BYTES_PER_CELL_UPDATE * own_cells / (iter_ms * 1e-3) / 1e9 if iter_ms > 0 else 0.0
         moved = (20.0 if dem32 else 24.0) * own_cells    # what the kernel really streams (DEM as 4-byte codes or fp64)
-        traffic = measured_traffic(n, ranks_used, args.kernel, dem32)
+        pmc = measured_counters(n, ranks_used, args.kernel, dem32) if args.module == "add" else {}
+        traffic = pmc.get("traffic")
+        hbm_real = traffic / (iter_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic and iter_ms > 0 else None
+        # VALU issue share measured with the counters, rescaled to THIS run's kernel time (the instruction count per launch
+        # is a property of the binary; the time is not)
+        valu = pmc.get("valu_issue_frac")
+        if valu and pmc.get("kernel_ms_at_collection") and iter_ms > 0:
+            valu = valu * pmc["kernel_ms_at_collection"] / iter_ms
+        bound = "hbm"
+        if valu and valu > (hbm_real if hbm_real is not None else moved / (iter_ms * 1e-3) / 1e9 / HBM_PEAK_GBS):
+            bound = "valu-issue (fp64; no MFMA in this path) ahead of hbm"
         out = {
             "metric": (f"cell-updates/sec on Add module, {n}x{n} DEM" if args.module == "add" else
                        f"cell-updates/sec on Drain module, {n}x{n} DEM (BASELINE config 5)"),
@@ -417,17 +571,25 @@ def main():
                                    (f"synthetic {n}x{n} DEM (seed {n}), Drain from the add-100-mm state after "
                                     f"{args.drain_spinup} iterations, one block of {args.steps} iterations"),
                        "kernel": args.kernel, "driver": args.driver, "decomposition": decomposition,
-                       "exchange_every": args.exchange_every if ranks_used > 1 else None,
+                       "exchange_every": k_used if ranks_used > 1 else None,
+                       "exchange_every_requested": args.exchange_every if ranks_used > 1 else None,
                        "halo": halo if ranks_used > 1 else None, "rccl_ranks": rccl_ranks,
+                       "rccl": lib.dll.wdpm_comm_version().decode() if ranks_used > 1 and halo == "rccl" else None,
                        "dist_backend": backend if world > 1 else None,
                        "max_diff_m": max_diff,
                        **({"enqueue_us_per_iteration_per_rank": enqueue_us,
                            "halo_refresh_host_us_per_iteration_per_rank": refresh_us} if enqueue_us is not None else {}),
                        **({"drain_bookkeeping_ms_per_block": stats_s * 1e3} if stats_s is not None else {})},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": bound,
+                         # the whole job against N x 8 TB/s at the 24 algorithmic bytes: the figure that includes everything
+                         "job_frac": value * ALGO_BYTES_PER_CELL_UPDATE / 1e9 / (HBM_PEAK_GBS * ranks_used),
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": "profiles/traffic.json (rocprofv3 --pmc passes of this command, committed)"
-                                           if traffic is not None else None,
+                         # counter bytes / kernel time / 8 TB/s: what the memory system really carries
+                         "hbm_real_frac": hbm_real,
+                         # share of the kernel's cycles in which a SIMD issues a VALU instruction: the OTHER ceiling
+                         "valu_issue_frac": valu,
+                         "counters_source": ("profiles/traffic.json <- " + str(pmc.get("source"))) if pmc else None,
                          "dem": "32-bit codes, verified lossless on upload (20 B of HBM traffic per cell-update)" if dem32
                                 else "fp64 (24 B of HBM traffic per cell-update)",
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_CELL_UPDATE * own_cells,
@@ -437,12 +599,21 @@ def main():
                          "kernel": "the iteration kernel's plain instance: launches 2 .. K-1 of the block" if steady_launches > 0
                                    else "all launches of the block",
                          "kernel_ms_per_iteration_all_launches": all_ms,
-                         "frac_all_launches": ALGO_BYTES_PER_CELL_UPDATE * own_cells / (all_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if all_ms > 0 else 0.0,
-                         "job_frac": value * ALGO_BYTES_PER_CELL_UPDATE / 1e9 / (HBM_PEAK_GBS * ranks_used)},
+                         "frac_all_launches": ALGO_BYTES_PER_CELL_UPDATE * own_cells / (all_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if all_ms > 0 else 0.0},
         }
+        if degraded:
+            out["degraded"] = True
+            out["degraded_reason"] = degraded
         if not args.no_cpu_baseline and ranks_used == 1:   # rank 0 at N=1 only
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(full=args.cpu_baseline_full)
         print(json.dumps(out), flush=True)
+    if degraded:
+        # a helper thread may still sit inside the RCCL call that never came back: leave without running anybody's destructors
+        if world > 1:
+            dist.barrier()
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
     closer()
     if world > 1:
         dist.barrier()

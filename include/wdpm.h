@@ -204,6 +204,14 @@ int wdpm_comm_size(wdpm_ctx *ctx, int32_t *nranks, int32_t *rank);   /* as RCCL 
 int wdpm_comm_exchange(wdpm_ctx *ctx, int32_t nsend, const wdpm_halo_op *sends, int32_t nrecv, const wdpm_halo_op *recvs);
 /* all[r*n + i] = mine[i] of rank r on every rank (n <= 8); synchronous */
 int wdpm_comm_allgather(wdpm_ctx *ctx, const double *mine, int32_t n, double *all);
+/* Deadlines: communicator set-up and the first transfer / all-gather of a communicator run with a deadline
+ * (WDPM_RCCL_TIMEOUT_S, default 90 s), and so does every wait for the stream of a context that has a communicator
+ * (WDPM_SYNC_TIMEOUT_S, default 600 s): past it the call returns 1 and the communicator is aborted.
+ * wdpm_comm_abort ends a context's communicator at once (ncclCommAbort; no-op without one): its queued transfers end,
+ * the peers' matching ones fail instead of waiting for rows that never come.  Callable from another thread than the one
+ * driving the context - a rank of a group that fails aborts every rank's (the reference exits on any device error,
+ * WDPMCL.c:92-118,225-232; so does WDPMCL here, non-zero, instead of hanging). */
+int wdpm_comm_abort(wdpm_ctx *ctx);
 
 /* -- row-block decomposition: the raster over several GPUs (wdpm_rowblock.c, both libraries) ------
  * New work relative to the single-device reference.  Rank g owns padded rows

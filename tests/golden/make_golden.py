@@ -301,7 +301,11 @@ def make_full_size(ref):
 
     for name, n, add_iters, drain_iters, every in (("cfg3_add_4096_i20", 4096, 20, 0, 512),
                                                    ("cfg4_add_16384_i2", 16384, 2, 0, 4096),
-                                                   ("cfg5_drain_8192_a3_d5", 8192, 3, 5, 2048)):
+                                                   ("cfg5_drain_8192_a3_d5", 8192, 3, 5, 2048),
+                                                   # nine iterations: with the default exchange interval (k = 4) the halos are
+                                                   # refreshed twice and a ninth iteration consumes the second refresh
+                                                   ("cfg4_add_16384_i9", 16384, 9, 0, 4096),
+                                                   ("cfg5_drain_8192_a3_d9", 8192, 3, 9, 2048)):
         dem = gen.synth_dem(n, n)
         bd, bw = pad(dem, np.full((n, n), 0.1), missing)            # add 100 mm, rof 1.0 on an empty water raster
         del dem

@@ -19,6 +19,11 @@ def run(rank, world, port, libpath, case, outdir):
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     lib = wdpm_amd.load(libpath)
     dem, water, miss = random_case(case["seed"], case["R"], case["C"])
+    if case.get("ponds"):                         # mostly dry: dry tiles, water arriving through refreshed halos
+        water[:, :] = 0.0
+        for r0, r1, c0, c1, d in case["ponds"]:
+            water[r0:r1, c0:c1] = d
+        water[dem <= miss] = 0.0
     bd, bw = pad(dem, water, miss)
     kw = dict(case.get("ctx_kw", {}))
     drain = case["module"] == "drain"
@@ -32,8 +37,15 @@ def run(rank, world, port, libpath, case, outdir):
                 self.error = RuntimeError("simulated: transport refused")
                 return 1
         transport = Refusing(dist)
-    s = RowBlockSolver(lib, case["module"], case["R"], case["C"], miss, rank=rank, nranks=world,
-                       exchange_every=case["k"], transport=transport, dist=dist, **kw)
+    if case.get("halo") == "rccl":
+        # halos through the library's own RCCL path, one process per rank: wdpm_comm_unique_id on rank 0 -> broadcast (gloo) ->
+        # ncclCommInitRank -> grouped ncclSend/ncclRecv on the context's stream, ncclAllGather for the block scalars
+        s = RowBlockSolver(lib, case["module"], case["R"], case["C"], miss, rank=rank, nranks=world,
+                           exchange_every=case["k"], halo="rccl", dist=dist, **kw)
+        assert s.rccl_ranks() == world
+    else:
+        s = RowBlockSolver(lib, case["module"], case["R"], case["C"], miss, rank=rank, nranks=world,
+                           exchange_every=case["k"], transport=transport, dist=dist, **kw)
     s.upload_global(bd, bw)
     if drain:
         s.set_totaldrain(max(bw[dr, dc], 0.0))

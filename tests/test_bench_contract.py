@@ -10,7 +10,7 @@ import pytest
 
 from conftest import ROOT
 
-pytestmark = pytest.mark.gpu
+gpu = pytest.mark.gpu
 
 
 def run_bench(*args):
@@ -22,6 +22,7 @@ def run_bench(*args):
     return json.loads(lines[0])
 
 
+@gpu
 def test_bench_line_has_the_contract_fields():
     d = run_bench("--size", "1024", "--steps", "7", "--warmup", "2")
     assert d["metric"] == "cell-updates/sec on Add module, 1024x1024 DEM" and d["unit"] == "cell-updates/s"
@@ -32,34 +33,55 @@ def test_bench_line_has_the_contract_fields():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0
-    assert r["traffic"] is None and r["traffic_source"] is None   # PMC traffic is only quoted for the configuration it was measured on
+    assert list(r)[:2] == ["bound", "job_frac"] and 0 < r["job_frac"] <= r["frac_all_launches"] * 1.001
+    # counter evidence (HBM bytes, VALU issue share) is only quoted for the configuration it was measured on
+    assert r["traffic"] is None and r["hbm_real_frac"] is None and r["valu_issue_frac"] is None and r["counters_source"] is None
     # the dominant kernel is the plain instance (launches 2 .. K-1); the all-launch average (flush-on-load first launch,
     # max-diff last launch included) is reported beside it
     assert r["kernel_ms_per_iteration"] > 0 and r["kernel_ms_per_iteration_all_launches"] > 0 and "launches 2" in r["kernel"]
     assert abs(r["moved_frac"] * r["peak"] * r["kernel_ms_per_iteration"] * 1e6 - r["moved_bytes_per_launch"]) < 1e-6 * r["moved_bytes_per_launch"]
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["value"] > 0 and c["unit"] == "cell-updates/s"
-    assert "iterations" in c["sample"]
+    assert "iterations" in c["sample"] and c["cpu_model"] and c["host_cores"] >= 1
+    # SURVEY §8d's samples: 1024^2 x 1000 always (16384^2 x 10 behind --cpu-baseline-full), next to the headline 4096^2 x 24
+    assert [(x["size"], x["iterations"]) for x in c["samples"]] == [(4096, 24), (1024, 1000)] and c["value"] == c["samples"][0]["value"]
 
 
+def test_counter_evidence_is_quoted_for_the_headline_configuration():
+    """profiles/traffic.json: HBM bytes and VALU issue share per launch of the dominant kernel, from committed rocprofv3
+    PMC passes of the default command - what `roofline.traffic / hbm_real_frac / valu_issue_frac` quote (no GPU needed)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_counters", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    c = mod.measured_counters(16384, 1, "auto", True)
+    assert 0.8 * 20 * 16384 ** 2 < c["traffic"] < 24 * 16384 ** 2 and 0.5 < c["valu_issue_frac"] < 1.0 and c["kernel_ms_at_collection"] > 0
+    assert os.path.exists(os.path.join(ROOT, c["source"].split(" ")[0]))
+    assert mod.measured_counters(4096, 1, "auto", True) == {} and mod.measured_counters(16384, 2, "auto", True) == {}
+
+
+@gpu
 def test_bench_drain_line():
     d = run_bench("--module", "drain", "--size", "1024", "--steps", "5", "--warmup", "1", "--drain-spinup", "20",
                   "--no-cpu-baseline")
     assert d["metric"].startswith("cell-updates/sec on Drain module") and d["value"] > 0 and "cpu_baseline" not in d
 
 
+@gpu
 def test_bench_starts_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher: the ranks are child processes of bench.py (one GPU here, so
-    they share it: gloo + host-staged halos - the driver's multi-GPU boxes get nccl + RCCL halos), ONE line out"""
+    they share it: host-staged halos over gloo - the driver's multi-GPU boxes get RCCL halos), ONE line out"""
     d = run_bench("--gpus", "2", "--size", "1536", "--steps", "12", "--warmup", "3", "--exchange-every", "2")
     assert d["n_gpus"] == 2 and d["steps"] == 12 and d["value"] > 0
     c = d["config"]
     assert c["driver"] == "ranks" and c["halo"] == "host" and c["dist_backend"] == "gloo" and c["rccl_ranks"] is None
-    assert "cpu_baseline" not in d
+    assert c["exchange_every"] == 2 and c["exchange_every_requested"] == 2
+    assert "cpu_baseline" not in d and "degraded" not in d
     one = run_bench("--size", "1536", "--steps", "12", "--warmup", "3", "--no-cpu-baseline")
     assert one["config"]["max_diff_m"] == c["max_diff_m"]          # same block, same bits
 
 
+@gpu
 def test_bench_group_driver():
     """--driver group: all ranks inside bench.py's process, one host thread per slab (what WDPMCL does)"""
     d = run_bench("--gpus", "3", "--driver", "group", "--size", "1536", "--steps", "12", "--warmup", "3",
@@ -69,6 +91,7 @@ def test_bench_group_driver():
     assert c["enqueue_us_per_iteration_per_rank"] > 0
 
 
+@gpu
 def test_bench_ranks_fall_back_together_when_real_rccl_refuses():
     """Two ranks on the ONE GPU of the test box with RCCL halos forced: both processes take the id rank 0 made, both call
     ncclCommInitRank of the real RCCL - which refuses two ranks on one device - and then ALL ranks switch to host-staged halos
@@ -78,12 +101,14 @@ def test_bench_ranks_fall_back_together_when_real_rccl_refuses():
                         "--exchange-every", "2", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert p.returncode == 0, p.stderr[-2000:]
     d = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][-1])
-    assert "RCCL halos refused" in p.stderr and "CommInitRank" in p.stderr
+    assert "RCCL halos are not to be had" in p.stderr and "CommInitRank" in p.stderr
     assert d["n_gpus"] == 2 and d["config"]["halo"].startswith("host") and d["value"] > 0
+    assert d["degraded"] is True and "CommInitRank" in d["degraded_reason"]      # not to be mistaken for a GPU-direct result
     one = run_bench("--size", "1536", "--steps", "12", "--warmup", "3", "--no-cpu-baseline")
     assert one["config"]["max_diff_m"] == d["config"]["max_diff_m"]
 
 
+@gpu
 def test_bench_launcher_starts_the_ranks_again_when_the_nccl_backend_fails():
     """the same two ranks with torch.distributed's nccl backend forced as well: that backend itself fails on a shared device,
     the rank processes die - and bench.py's own launcher starts them once more with host-staged halos over gloo"""
@@ -91,6 +116,15 @@ def test_bench_launcher_starts_the_ranks_again_when_the_nccl_backend_fails():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "1536", "--steps", "12", "--warmup", "3",
                         "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert p.returncode == 0, p.stderr[-2000:]
-    assert "starting them again with host-staged halos over gloo" in p.stderr
+    assert "starting them once more with host-staged halos over gloo" in p.stderr and "budget" in p.stderr
     d = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][-1])
     assert d["n_gpus"] == 2 and d["config"]["halo"] == "host" and d["config"]["dist_backend"] == "gloo" and d["value"] > 0
+    assert d["degraded"] is True and "exit status" in d["first_attempt"]
+
+
+@gpu
+def test_bench_reports_the_exchange_interval_the_library_used():
+    """slabs too short for the interval asked for: the library shrinks it (every rank the same way) and the line says both"""
+    d = run_bench("--gpus", "4", "--size", "256", "--steps", "6", "--warmup", "1", "--exchange-every", "12", "--no-cpu-baseline")
+    c = d["config"]
+    assert d["n_gpus"] == 4 and c["exchange_every_requested"] == 12 and 1 <= c["exchange_every"] < 12

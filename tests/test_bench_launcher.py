@@ -64,16 +64,41 @@ def test_launcher_retries_a_lost_port_race(bench, monkeypatch, capsys):
 
 def test_launcher_falls_back_to_host_halos_when_ranks_fail(bench, monkeypatch, capsys):
     rc, io, calls = run(bench, monkeypatch, capsys, [(1, "", "ncclCommInitRank: unhandled system error\n"), (0, LINE + "\n", "")])
-    assert rc == 0 and io.out.strip() == LINE and len(calls) == 2
+    assert rc == 0 and io.out.strip().startswith(LINE[:-1]) and len(calls) == 2
     assert calls[1][1]["WDPM_HALO"] == "host" and calls[1][1]["WDPM_DIST_BACKEND"] == "gloo"
     assert "host-staged halos" in io.err and "unhandled system error" in io.err
+    import json
+    d = json.loads(io.out)
+    assert d["degraded"] is True and "exit status 1" in d["first_attempt"]     # a second run is never passed off as the first
 
 
 def test_launcher_falls_back_when_ranks_hang(bench, monkeypatch, capsys):
     monkeypatch.setenv("WDPM_BENCH_RANKS_TIMEOUT", "0.01")
     rc, io, calls = run(bench, monkeypatch, capsys, [("hang", "", ""), (0, LINE + "\n", "")])
-    assert rc == 0 and io.out.strip() == LINE and calls[1][1]["WDPM_HALO"] == "host"
-    assert "did not finish" in io.err
+    import json
+    assert rc == 0 and json.loads(io.out)["degraded"] is True and calls[1][1]["WDPM_HALO"] == "host"
+    assert "no result within" in io.err and "budget" in io.err
+
+
+def test_launcher_keeps_both_attempts_inside_the_time_budget(bench, monkeypatch, capsys):
+    """the driver ends bench.py after 600 s: the first attempt gets at most 200 s by default, the second what is left of 560"""
+    seen, clock = [], [1000.0]
+    monkeypatch.setattr(bench.time, "monotonic", lambda: clock[0])
+
+    class Timed(FakePopen):
+        def communicate(self, timeout=None):
+            seen.append(timeout)
+            if self.rc == "hang" and timeout is not None:
+                clock[0] += timeout                         # a hung run uses up its whole limit
+            return super().communicate(timeout)
+    FakePopen.script, FakePopen.calls = [("hang", "", ""), (0, LINE + "\n", "")], []
+    monkeypatch.setattr(subprocess, "Popen", Timed)
+    assert bench.self_launch(argparse.Namespace(gpus=2)) == 0
+    limits = [t for t in seen if t is not None]
+    assert limits[0] <= 200.0 and limits[0] + limits[1] <= 560.0
+    monkeypatch.setenv("WDPM_BENCH_BUDGET_S", "15")           # no room for a second attempt: none is made
+    FakePopen.script, FakePopen.calls = [("hang", "", ""), (0, LINE + "\n", "")], []
+    assert bench.self_launch(argparse.Namespace(gpus=2)) == 124 and len(FakePopen.calls) == 1
 
 
 def test_launcher_gives_up_after_the_second_transport(bench, monkeypatch, capsys):

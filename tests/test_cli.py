@@ -279,7 +279,7 @@ def test_hip_cli_add300_to_convergence(workdir, golden):
     print(f"WDPMCL add 300 mm to convergence on the HIP path: {dt:.1f} s wall (reference serial: 412 s)")
 
 
-def test_cli_report_backend_line_and_gdaldem_handoff(workdir, golden):
+def backend_line_and_gdaldem_handoff(exe, backend, workdir, golden):
     """opt-in conveniences for the GUI side.  WDPM_REPORT_BACKEND=1 adds ONE line to the report (and
     nothing else changes); WDPM_COLOR_RELIEF=<map> hands the output raster to `gdaldem color-relief` the way the
     reference's src/cmap_black.sh does (a stand-in `gdaldem` on PATH records how it was called)"""
@@ -292,10 +292,10 @@ def test_cli_report_backend_line_and_gdaldem_handoff(workdir, golden):
     open(os.path.join(workdir, "colormap_black.txt"), "w").write("3,25,0,230\n0.001,25,0,230\n0,yellow\n-9999, black\n")
     env = dict(os.environ, WDPM_REPORT_BACKEND="1", WDPM_COLOR_RELIEF="colormap_black.txt",
                PATH=fake + os.pathsep + os.environ["PATH"])
-    p = subprocess.run([ORACLE_CLI] + g["args"], cwd=workdir, capture_output=True, text=True, timeout=600, env=env)
+    p = subprocess.run([exe] + g["args"], cwd=workdir, capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, p.stderr
     extra = [ln for ln in p.stdout.splitlines() if "Computation back-end:" in ln]
-    assert len(extra) == 1 and "oracle-cpu, 1 device" in extra[0]
+    assert len(extra) == 1 and f"{backend}, 1 device" in extra[0]
     rest = "\n".join(ln for ln in p.stdout.splitlines() if "Computation back-end:" not in ln) + "\n"
     assert hashlib.sha256(strip_timing(rest).encode()).hexdigest() == g["report_sha256_nontiming"]
     assert file_sha(os.path.join(workdir, "a300.asc")) == g["out_sha256"]
@@ -303,3 +303,14 @@ def test_cli_report_backend_line_and_gdaldem_handoff(workdir, golden):
         ["color-relief", "a300.asc", "colormap_black.txt", "-OF", "png", "a300.png"]
     assert os.path.exists(os.path.join(workdir, "a300.png")) and not os.path.exists(os.path.join(workdir, "a300.png.aux.xml"))
     assert "colour relief written to a300.png" in p.stderr
+
+
+def test_cli_report_backend_line_and_gdaldem_handoff(workdir, golden):
+    backend_line_and_gdaldem_handoff(ORACLE_CLI, "oracle-cpu", workdir, golden)
+
+
+@pytest.mark.gpu
+def test_hip_cli_report_backend_line_and_gdaldem_handoff(workdir, golden):
+    """the same on the SHIPPED binary (wdpm_amd/bin/WDPMCL, HIP path): the helper that runs gdaldem is forked before
+    anything touches the GPU - a process that has initialised it must not exec another program on this pool"""
+    backend_line_and_gdaldem_handoff(HIP_CLI, "hip-gfx950", workdir, golden)

@@ -1,10 +1,16 @@
 """BASELINE configs 3, 4 and 5 at FULL size against the unmodified reference.
 
-tests/golden/full_size.npz holds, for 4096^2 add x20, 16384^2 add x2 and 8192^2 add x3 + drain x5 on the
-synthetic DEMs, what the reference's own runoffs()/runoffd()/drain() produce (tests/golden/make_golden.py,
+tests/golden/full_size.npz holds, for 4096^2 add x20, 16384^2 add x2 and x9, 8192^2 add x3 + drain x5 and x9 on
+the synthetic DEMs, what the reference's own runoffs()/runoffd()/drain() produce (tests/golden/make_golden.py,
 run where /root/reference exists): sha256 of the padded water raster, an 8-byte hash of every row (says
 which rows differ when the whole hash does), sampled rows, max diff, totaldrain and the sequential
-volume sum.  Bit-exact is the bar: every comparison below is on hashes of the fp64 bits."""
+volume sum.  Bit-exact is the bar: every comparison below is on hashes of the fp64 bits.
+
+What is pinned, exactly: one context at 2 / 20 iterations (both kernels, DEM codes on and off, another chunk
+height); row blocks at 16384^2 with exchange interval k = 1 (4 slabs) and k = 2 (8 slabs) over 2 iterations, and
+with the DEFAULT k = 4 on 8 slabs over 9 iterations - two halo refreshes and a ninth iteration that consumes the
+second - once over peer copies and once over the stand-in RCCL (tests/mock_rccl); drain at 8192^2 on 1 and 3 slabs
+(k = 2, 5 iterations) and on 8 slabs at the default k = 4 over 9 iterations, again over both transports."""
 import hashlib
 import json
 import os
@@ -105,6 +111,77 @@ def test_row_blocks_at_16384_equal_the_reference(hip, golden, devices, k):
 
 
 @pytest.mark.gpu
+def test_row_blocks_at_the_default_exchange_interval_equal_the_reference(hip, golden):
+    """config 4 as bench.py and WDPMCL run it by default: 8 row blocks, halos refreshed every FOUR iterations; nine
+    iterations, so that the ninth runs on halos refreshed under that schedule (reference loop: WDPMCL.c:1094-1106)"""
+    from wdpm_amd.rowblock import Group
+    z, idx = golden
+    meta = idx["cfg4_add_16384_i9"]
+    n = meta["n"]
+    bd, bw = inputs(hip, n)
+    with Group(hip, "add", n, n, MISS, [0] * 8) as g:              # exchange_every: the default
+        assert g.size == 8
+        import ctypes as C
+        k = C.c_int32()
+        hip.check(hip.dll.wdpm_rank_info(hip.dll.wdpm_group_rank(g._h, 0), None, C.byref(k), None))
+        assert k.value == 4
+        g.upload(bd, bw)
+        md = g.run_block(meta["add_iters"], THRES)
+        w = g.download_water()
+    assert md == meta["max_diff"]
+    assert_matches(z, meta, w)
+
+
+@pytest.mark.gpu
+def test_default_schedule_over_the_standin_rccl_equals_the_reference(hip):
+    """the same two full-size jobs (add 16384^2 x9, drain 8192^2 x9; 8 slabs, k = 4) with the halos going through the
+    library's RCCL path (wdpm_comm_exchange on each rank's stream; the wire is tests/mock_rccl) - in a child process,
+    because the stand-in has to be bound before the library looks for RCCL"""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "mock_rccl")], stdout=subprocess.DEVNULL)
+    env = dict(os.environ, WDPM_RCCL_LIB=os.path.join(ROOT, "tests", "mock_rccl", "libmock_rccl.so"), WDPM_HALO="rccl",
+               WDPM_RCCL_SHARED_DEVICE_OK="1", WDPM_FULL_SIZE_WORKER="1")
+    p = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    assert "FULL_SIZE_RCCL_OK add" in p.stdout and "FULL_SIZE_RCCL_OK drain" in p.stdout, p.stdout
+
+
+def drain_job(hip, z, meta, devices, k):
+    from wdpm_amd.rowblock import Group
+    n = meta["n"]
+    bd, bw = inputs(hip, n)
+    with hip.context(module="add", nrows=n, ncols=n, missingvalue=MISS) as c:
+        c.upload(bd, bw)
+        c.iterate(meta["add_iters"])
+        w3 = c.download_water()
+    dr, dc = meta["drainrow"], meta["draincol"]
+    kw = dict(exchange_every=k) if k else {}
+    with Group(hip, "drain", n, n, MISS, devices, drainrow=dr, draincol=dc, **kw) as g:
+        assert g.size == len(devices)
+        g.upload(bd, w3)
+        g.set_totaldrain(meta["td0"])
+        md = g.run_block(meta["drain_iters"], THRES)
+        diffdrain, vol = g.drain_stats()
+        td = g.totaldrain()
+        w = g.download_water()
+        halo = g.halo_kind
+    assert md == meta["max_diff"] and td == meta["totaldrain"]
+    assert diffdrain == abs(meta["totaldrain"] - meta["td0"])
+    assert vol == meta["volume_sum"]
+    assert_matches(z, meta, w)
+    return halo
+
+
+@pytest.mark.gpu
+def test_drain_on_8_slabs_at_the_default_interval_equals_the_reference(hip, golden):
+    """config 5's decomposition: 8 row blocks, default exchange interval, nine drain iterations (WDPMCL.c:1076-1093)"""
+    z, idx = golden
+    drain_job(hip, z, idx["cfg5_drain_8192_a3_d9"], [0] * 8, None)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("devices", [[0], [0, 0, 0]])
 def test_drain_at_8192_equals_the_reference(hip, golden, devices):
     """config 5 at full size: add x3, flush, drain x5 - water, max diff, totaldrain and the sequential
@@ -133,3 +210,26 @@ def test_drain_at_8192_equals_the_reference(hip, golden, devices):
     assert diffdrain == abs(meta["totaldrain"] - meta["td0"])
     assert vol == meta["volume_sum"]
     assert_matches(z, meta, w)
+
+
+if __name__ == "__main__" and os.environ.get("WDPM_FULL_SIZE_WORKER"):
+    # child of test_default_schedule_over_the_standin_rccl_equals_the_reference (WDPM_RCCL_LIB points at the stand-in)
+    import wdpm_amd as _w
+    from wdpm_amd.rowblock import Group as _Group
+    _hip = _w.load_hip()
+    assert b"2.99.99" in _hip.dll.wdpm_comm_version()
+    _z = np.load(os.path.join(GOLDEN, "full_size.npz"))
+    _idx = {m["name"]: m for m in json.loads(bytes(_z["index_json"]).decode())}
+    _meta = _idx["cfg4_add_16384_i9"]
+    _bd, _bw = inputs(_hip, _meta["n"])
+    with _Group(_hip, "add", _meta["n"], _meta["n"], MISS, [0] * 8) as _g:
+        assert _g.size == 8 and _w.HALO_NAMES[_g.halo_kind] == "rccl"
+        _g.upload(_bd, _bw)
+        _md = _g.run_block(_meta["add_iters"], THRES)
+        _wat = _g.download_water()
+    assert _md == _meta["max_diff"]
+    assert_matches(_z, _meta, _wat)
+    del _bd, _bw, _wat
+    print("FULL_SIZE_RCCL_OK add", flush=True)
+    assert _w.HALO_NAMES[drain_job(_hip, _z, _idx["cfg5_drain_8192_a3_d9"], [0] * 8, None)] == "rccl"
+    print("FULL_SIZE_RCCL_OK drain", flush=True)

@@ -2,7 +2,11 @@
 tests/mock_rccl/libmock_rccl.so stands in for it (WDPM_RCCL_LIB): ncclSend / ncclRecv become event-ordered
 device-to-device copies, everything above the wire is the product's code - wdpm_comm_init_all, the rank threads each
 issuing their own grouped send/recv on their context's stream, the refresh between iteration groups with the
-overlapped last iteration, tile flags and the folded max diff around a refresh, the drain module's scalars."""
+overlapped last iteration, tile flags and the folded max diff around a refresh, the drain module's scalars.
+Second half: the same with ONE PROCESS PER RANK, the way bench.py's ranks and the driver's 8-GPU run go -
+wdpm_comm_unique_id -> broadcast -> ncclCommInitRank -> send/recv through IPC-mapped device memory -> ncclAllGather -
+including bench.py itself on two and eight ranks, and its way out when set-up or the first transfer never comes back."""
+import json
 import os
 import subprocess
 import sys
@@ -10,6 +14,7 @@ import sys
 import pytest
 
 from conftest import ROOT
+from helpers import bits_equal, n_bit_diff
 
 pytestmark = pytest.mark.gpu
 MOCK = os.path.join(ROOT, "tests", "mock_rccl", "libmock_rccl.so")
@@ -47,3 +52,89 @@ def test_cli_on_three_slabs_with_rccl_halos(mock_env, tmp_path):
     assert "halos by RCCL send/recv" in p.stderr
     assert hashlib.sha256(strip_timing(p.stdout).encode()).hexdigest() == g["report_sha256_nontiming"]
     assert file_sha(os.path.join(tmp_path, "a300.asc")) == g["out_sha256"]
+
+
+# ---- one process per rank ---------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def proc_env(mock_env):
+    return dict(mock_env, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+
+
+@pytest.mark.parametrize("module,R,C,world,k,blocks,ponds", [
+    ("add", 300, 420, 2, 3, [13, 8], None),
+    ("drain", 330, 250, 3, 1, [7, 5], None),
+    ("drain", 240, 380, 2, 2, [9, 6], None),
+    # big enough for the marching kernel, the overlapped last iteration, dry tiles and the folded max diff
+    ("add", 1300, 1100, 3, 4, [21, 10], [[100, 160, 300, 420, 0.3], [900, 960, 100, 200, 0.2]]),
+])
+def test_rank_processes_with_rccl_halos_equal_one_context(oracle, hip, proc_env, module, R, C, world, k, blocks, ponds):
+    """wdpm_rank_create with an id in `world` PROCESSES sharing the GPU: owned rows, every block's max diff and the drain
+    module's scalars (through ncclAllGather, rank-chained volume sum included) equal one context's"""
+    from test_rowblock import run_ranks, single
+    case = dict(seed=70 + world, R=R, C=C, module=module, k=k, thres=1e-4, blocks=blocks, halo="rccl", ctx_kw=dict(device=0))
+    if ponds:
+        case["ponds"] = ponds
+    ref = dict(case, ctx_kw={})
+    want, mds = single(oracle, ref)
+    got = run_ranks(world, case, libpath=hip.path, env=proc_env)
+    for g in got:
+        lo, hi = int(g["lo"]), int(g["hi"])
+        assert bits_equal(g["own"], want[lo:hi + 1]), f"rows {lo}..{hi}: {n_bit_diff(g['own'], want[lo:hi + 1])} cells differ"
+        assert list(g["mds"]) == mds
+        if module == "drain":
+            assert g["stats"].tolist() == ref["_stats"]
+
+
+def bench_line(env, *args, timeout=600):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args, "--no-cpu-baseline"], capture_output=True,
+                       text=True, timeout=timeout, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, p.stdout + p.stderr[-2000:]
+    return json.loads(lines[0]), p.stderr
+
+
+@pytest.fixture(scope="module")
+def one_rank_line():
+    return bench_line(dict(os.environ), "--size", "2048", "--steps", "13", "--warmup", "3")[0]
+
+
+def test_bench_ranks_over_mock_rccl_processes(proc_env, one_rank_line):
+    """bench.py --gpus 2 as the driver's launcher runs it (torch.distributed.run, one process per rank), halos by the
+    library's RCCL path over the stand-in: gloo control plane, communicator from the broadcast id, the rehearsal block,
+    K timed steps ending in ncclAllGather - and the same bits as one rank"""
+    d, err = bench_line(proc_env, "--gpus", "2", "--size", "2048", "--steps", "13", "--warmup", "3")
+    c = d["config"]
+    assert d["n_gpus"] == 2 and c["halo"] == "rccl" and c["rccl_ranks"] == 2 and c["dist_backend"] == "gloo", c
+    assert "degraded" not in d and "2.99.99" in c["rccl"] and c["exchange_every"] == 4
+    assert c["max_diff_m"] == one_rank_line["config"]["max_diff_m"]
+    assert "sends over" in err                              # the stand-in says which wire ran (IPC-mapped memory or a file)
+
+
+def test_bench_eight_ranks_over_mock_rccl_processes(proc_env):
+    """the driver's N = 8 command shape on the one GPU of this box (5 ranks: the pool allows six GPU processes)"""
+    d5, _ = bench_line(proc_env, "--gpus", "5", "--size", "4096", "--steps", "20", "--warmup", "5")
+    d1, _ = bench_line(dict(os.environ), "--size", "4096", "--steps", "20", "--warmup", "5")
+    assert d5["n_gpus"] == 5 and d5["config"]["halo"] == "rccl" and d5["config"]["rccl_ranks"] == 5 and "degraded" not in d5
+    assert d5["config"]["max_diff_m"] == d1["config"]["max_diff_m"]
+
+
+def test_bench_goes_on_with_host_halos_when_communicator_setup_hangs(proc_env, one_rank_line):
+    """rank 1's ncclCommInitRank does not come back: the library's deadline ends the wait, ALL ranks agree and finish on
+    host-staged halos in the same processes - a line marked degraded, the same bits, well inside the driver's 600 s"""
+    env = dict(proc_env, MOCK_RCCL_HANG_INIT_RANK="1", MOCK_RCCL_HANG_S="25", WDPM_RCCL_TIMEOUT_S="4", MOCK_RCCL_TIMEOUT_S="8")
+    d, err = bench_line(env, "--gpus", "2", "--size", "2048", "--steps", "13", "--warmup", "3", timeout=300)
+    assert d["degraded"] is True and "did not return within" in d["degraded_reason"], d
+    assert d["config"]["halo"].startswith("host") and d["config"]["rccl_ranks"] is None
+    assert d["config"]["max_diff_m"] == one_rank_line["config"]["max_diff_m"]
+    assert "every rank switches to host-staged halos" in err
+
+
+def test_bench_goes_on_with_host_halos_when_the_first_transfer_never_completes(proc_env, one_rank_line):
+    """the first halo transfer is queued and the stream never moves on (for 12 s here): the stream wait's deadline ends
+    it, the communicator is aborted, all ranks finish on host-staged halos"""
+    env = dict(proc_env, MOCK_RCCL_STALL_RECV_S="12", WDPM_SYNC_TIMEOUT_S="3")
+    d, err = bench_line(env, "--gpus", "2", "--size", "2048", "--steps", "13", "--warmup", "3", timeout=300)
+    assert d["degraded"] is True and "did not finish within" in d["degraded_reason"], d
+    assert d["config"]["halo"].startswith("host")
+    assert d["config"]["max_diff_m"] == one_rank_line["config"]["max_diff_m"]

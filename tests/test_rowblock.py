@@ -35,6 +35,11 @@ def run_ranks(world, case, libpath=ORACLE_SO, env=None):
 
 def single(oracle, case):
     dem, water, miss = random_case(case["seed"], case["R"], case["C"])
+    if case.get("ponds"):
+        water[:, :] = 0.0
+        for r0, r1, c0, c1, d in case["ponds"]:
+            water[r0:r1, c0:c1] = d
+        water[dem <= miss] = 0.0
     bd, bw = pad(dem, water, miss)
     kw = {}
     if case["module"] == "drain":

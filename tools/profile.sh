@@ -16,10 +16,14 @@ out = sys.argv[1]; res = {}
 for d in ('fetch', 'write', 'sq'):
     for f in glob.glob(f'{out}/{d}/*/*_counter_collection.csv'):
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        seen = set()
         for r in csv.DictReader(open(f)):
             # template arguments kept: <0,..> is add/subtract, <2,..> drain, the third the DEM-code variant
             name = r['Kernel_Name'].split('(anonymous namespace)::')[-1].split('(')[0].replace('void ', '').strip()
             agg[name][r['Counter_Name']].append(float(r['Counter_Value']))
+            if d == 'sq' and r['Dispatch_Id'] not in seen:      # the kernel's duration while the counters were taken
+                seen.add(r['Dispatch_Id'])
+                agg[name]['kernel_ms'].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6)
         for k, c in agg.items():
             for cn, v in c.items():
                 res.setdefault(k, {})[cn] = {"n": len(v), "mean": sum(v) / len(v)}

@@ -110,6 +110,7 @@ SYMBOLS = {
     "wdpm_comm_size": (C.c_int, [_vp, _ip, _ip]),
     "wdpm_comm_exchange": (C.c_int, [_vp, C.c_int32, C.POINTER(HaloOp), C.c_int32, C.POINTER(HaloOp)]),
     "wdpm_comm_allgather": (C.c_int, [_vp, _dp, C.c_int32, _dp]),
+    "wdpm_comm_abort": (C.c_int, [_vp]),
     "wdpm_partition": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(SlabStruct)]),
     "wdpm_rank_create": (C.c_int, [C.POINTER(_vp), C.POINTER(Params), C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp, _vp]),
     "wdpm_rank_destroy": (None, [_vp]),

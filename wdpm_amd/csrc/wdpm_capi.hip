@@ -11,6 +11,8 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <time.h>
+
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -51,6 +53,34 @@ static int tiles_touch(wdpm_ctx *x, int slot, int row, int nrows);
 int wdpm_tiles_touch(wdpm_ctx *x, int row, int nrows) { return tiles_touch(x, x->cur, row, nrows); }
 static int ensure_drained(wdpm_ctx *x);
 int wdpm_apply_owed_drain(wdpm_ctx *x) { return ensure_drained(x); }
+static int ensure_flushed(wdpm_ctx *x);
+int wdpm_apply_owed_flush(wdpm_ctx *x) { return ensure_flushed(x); }
+
+int wdpm_stream_sync(wdpm_ctx *x, hipStream_t s) {
+  if (!x->comm) {
+    const hipError_t e = hipStreamSynchronize(s);
+    return e == hipSuccess ? 0 : wdpm_fail("hipStreamSynchronize failed: %s", hipGetErrorString(e));
+  }
+  static std::atomic<int> limit_ms{0};
+  if (!limit_ms) { const char *t = getenv("WDPM_SYNC_TIMEOUT_S"); const double v = t ? atof(t) : 0.0; limit_ms = (int)((v > 0 ? v : 600.0) * 1000.0); }
+  timespec t0;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (;;) {
+    const hipError_t e = hipStreamQuery(s);
+    if (e == hipSuccess) return 0;
+    if (e != hipErrorNotReady) return wdpm_fail("hipStreamQuery failed: %s", hipGetErrorString(e));
+    timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    const double ms = (double)(t.tv_sec - t0.tv_sec) * 1e3 + (double)(t.tv_nsec - t0.tv_nsec) * 1e-6;
+    if (ms > (double)limit_ms) break;
+    if (ms > 5.0) { const timespec nap{0, 100000}; nanosleep(&nap, nullptr); }   /* short waits spin, long ones nap 0.1 ms */
+  }
+  /* a halo transfer whose peer never sent (or died): end the communicator so that the queue drains, and say so */
+  x->leak = true;
+  (void)wdpm_comm_abort(x);
+  return wdpm_fail("the GPU did not finish within %.0f s (WDPM_SYNC_TIMEOUT_S): a halo transfer did not complete; "
+                   "the communicator was aborted", limit_ms / 1000.0);
+}
 
 extern "C" {
 
@@ -174,8 +204,8 @@ static int guard_damage(wdpm_ctx *x, int64_t *bad) {
   const size_t g = guard_bytes();
   if (!g || x->guards.empty()) return 0;
   if (bind(x)) return 1;
-  HIP_TRY(hipStreamSynchronize(x->stream));
-  if (x->side) HIP_TRY(hipStreamSynchronize(x->side));
+  if (wdpm_stream_sync(x, x->stream)) return 1;
+  if (x->side && wdpm_stream_sync(x, x->side)) return 1;
   std::vector<unsigned char> h(g);
   for (const auto &gb : x->guards)
     for (int side = 0; side < 2; side++) {
@@ -232,6 +262,7 @@ int wdpm_create(wdpm_ctx **out, const wdpm_params *p) {
   x->steady_ms = 0.0;
   x->timing = false;
   x->comm = nullptr;
+  x->leak = false;
   x->d_dem = x->d_w[0] = x->d_w[1] = x->d_w[2] = nullptr;
   x->old = 2;
   for (int i = 0; i < 3; i++) { x->d_zero[i] = nullptr; x->zero_valid[i] = false; }
@@ -291,8 +322,9 @@ int wdpm_create(wdpm_ctx **out, const wdpm_params *p) {
 void wdpm_destroy(wdpm_ctx *x) {
   if (!x) return;
   (void)hipSetDevice(x->p.device);
-  (void)hipStreamSynchronize(x->stream);
+  if (!x->leak) (void)wdpm_stream_sync(x, x->stream);
   wdpm_comm_release(x);
+  if (x->leak) return;           /* a stuck transfer or helper thread may still touch the stream and the buffers: nothing is freed */
   if (x->side) { (void)hipStreamSynchronize(x->side); (void)hipStreamDestroy(x->side); }
   if (x->ev_fork) (void)hipEventDestroy(x->ev_fork);
   if (x->ev_join) (void)hipEventDestroy(x->ev_join);
@@ -315,7 +347,7 @@ void wdpm_destroy(wdpm_ctx *x) {
 
 int wdpm_set_stream(wdpm_ctx *x, void *hip_stream) {
   if (bind(x)) return 1;   /* also joins a pending interior launch onto the old stream */
-  HIP_TRY(hipStreamSynchronize(x->stream));
+  if (wdpm_stream_sync(x, x->stream)) return 1;
   if (x->own_stream && x->stream) HIP_TRY(hipStreamDestroy(x->stream));
   x->stream = (hipStream_t)hip_stream;
   x->own_stream = false;
@@ -324,7 +356,7 @@ int wdpm_set_stream(wdpm_ctx *x, void *hip_stream) {
 
 int wdpm_synchronize(wdpm_ctx *x) {
   if (bind(x)) return 1;
-  HIP_TRY(hipStreamSynchronize(x->stream));
+  if (wdpm_stream_sync(x, x->stream)) return 1;
   return 0;
 }
 
@@ -334,7 +366,7 @@ static int note_negzero(wdpm_ctx *x, int row, int nrows) {
   HIP_TRY(hipMemsetAsync(x->d_bits, 0, sizeof(unsigned long long), x->stream));
   HIP_TRY(wdpm_launch_scan_negzero(x->d_w[x->cur] + (size_t)row * x->g.ncp, (size_t)nrows * x->g.ncp, x->d_bits, x->stream));
   HIP_TRY(hipMemcpyAsync(x->h_pin, x->d_bits, sizeof(double), hipMemcpyDeviceToHost, x->stream));
-  HIP_TRY(hipStreamSynchronize(x->stream));
+  if (wdpm_stream_sync(x, x->stream)) return 1;
   unsigned long long bits;
   memcpy(&bits, x->h_pin, sizeof bits);
   if (bits) x->signed_zero_safe = true;
@@ -351,7 +383,7 @@ static int encode_dem(wdpm_ctx *x) {
   if (env && atoi(env) == 0) return 0;
   HIP_TRY(wdpm_launch_dem_min(x->d_dem, x->cells, x->d_bits, x->stream));
   HIP_TRY(hipMemcpyAsync(x->h_pin, x->d_bits, sizeof(double), hipMemcpyDeviceToHost, x->stream));
-  HIP_TRY(hipStreamSynchronize(x->stream));
+  if (wdpm_stream_sync(x, x->stream)) return 1;
   unsigned long long key;
   memcpy(&key, x->h_pin, sizeof key);
   if (key == ~0ull) return 0;                                  /* no valid cell at all */
@@ -362,7 +394,7 @@ static int encode_dem(wdpm_ctx *x) {
     if (!(fabs(k0) < 4.0e15)) break;                           /* k = q + k0 must stay an exact integer */
     HIP_TRY(wdpm_launch_dem_encode(x->d_dem, x->cells, k0, D, rD, x->d_dem32, x->d_bits, x->stream));
     HIP_TRY(hipMemcpyAsync(x->h_pin, x->d_bits, sizeof(double), hipMemcpyDeviceToHost, x->stream));
-    HIP_TRY(hipStreamSynchronize(x->stream));
+    if (wdpm_stream_sync(x, x->stream)) return 1;
     unsigned long long bad;
     memcpy(&bad, x->h_pin, sizeof bad);
     if (!bad) {
@@ -434,7 +466,7 @@ int wdpm_count_stats(wdpm_ctx *x, int32_t row_lo, int32_t row_hi, int64_t *valid
   HIP_TRY(wdpm_launch_count_stats(x->d_w[x->cur], x->d_dem, (size_t)row_lo * x->g.ncp, (size_t)row_hi * x->g.ncp, x->g.miss,
                                   x->d_stat, x->stream));
   HIP_TRY(hipMemcpyAsync(x->h_pin, x->d_stat, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, x->stream));
-  HIP_TRY(hipStreamSynchronize(x->stream));
+  if (wdpm_stream_sync(x, x->stream)) return 1;
   unsigned long long v[3];
   memcpy(v, x->h_pin, sizeof v);
   if (valid) *valid = (int64_t)v[0];
@@ -449,7 +481,7 @@ int wdpm_find_drain(wdpm_ctx *x, int32_t row_lo, int32_t row_hi, double *mindem,
   if (!x->d_stat) HIP_TRY(hipMalloc(&x->d_stat, 4 * sizeof(unsigned long long)));
   HIP_TRY(wdpm_launch_find_drain(x->d_dem, (size_t)row_lo * x->g.ncp, (size_t)row_hi * x->g.ncp, x->d_stat, x->stream));
   HIP_TRY(hipMemcpyAsync(x->h_pin, x->d_stat, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, x->stream));
-  HIP_TRY(hipStreamSynchronize(x->stream));
+  if (wdpm_stream_sync(x, x->stream)) return 1;
   unsigned long long v[2];
   memcpy(v, x->h_pin, sizeof v);
   if (v[0] == ~0ull || v[1] == ~0ull) { *row = -1; *col = -1; *mindem = __builtin_inf(); return 0; }
@@ -465,7 +497,7 @@ int wdpm_get_cell(wdpm_ctx *x, int32_t row, int32_t col, double *water, double *
   const size_t k = (size_t)row * x->g.ncp + col;
   HIP_TRY(hipMemcpyAsync(x->h_pin, x->d_w[x->cur] + k, sizeof(double), hipMemcpyDeviceToHost, x->stream));
   HIP_TRY(hipMemcpyAsync(x->h_pin + 1, x->d_dem + k, sizeof(double), hipMemcpyDeviceToHost, x->stream));
-  HIP_TRY(hipStreamSynchronize(x->stream));
+  if (wdpm_stream_sync(x, x->stream)) return 1;
   if (water) *water = x->h_pin[0];
   if (dem) *dem = x->h_pin[1] < __builtin_inf() ? x->h_pin[1] : x->g.miss;     /* the device marks NODATA as +inf */
   return 0;
@@ -482,7 +514,7 @@ int wdpm_download_unpadded(wdpm_ctx *x, int32_t file_row, int32_t nrows, int32_t
   x->zero_valid[st] = false;
   HIP_TRY(wdpm_launch_unpad(x->d_w[x->cur], x->d_dem, x->g, file_row, nrows, mask_missing, stage, x->stream));
   HIP_TRY(hipMemcpyAsync(dst, stage, (size_t)nrows * x->g.C * sizeof(double), hipMemcpyDeviceToHost, x->stream));
-  HIP_TRY(hipStreamSynchronize(x->stream));
+  if (wdpm_stream_sync(x, x->stream)) return 1;
   return 0;
 }
 
@@ -500,7 +532,7 @@ int wdpm_download_water(wdpm_ctx *x, double *bigwater) {
   if (bind(x)) return 1;
   if (ensure_flushed(x)) return 1;
   HIP_TRY(hipMemcpyAsync(bigwater, x->d_w[x->cur], x->cells * sizeof(double), hipMemcpyDeviceToHost, x->stream));
-  HIP_TRY(hipStreamSynchronize(x->stream));
+  if (wdpm_stream_sync(x, x->stream)) return 1;
   return 0;
 }
 
@@ -510,7 +542,7 @@ int wdpm_download_rows(wdpm_ctx *x, int32_t row, int32_t nrows, double *dst) {
   if (ensure_flushed(x)) return 1;
   HIP_TRY(hipMemcpyAsync(dst, x->d_w[x->cur] + (size_t)row * x->g.ncp, (size_t)nrows * x->g.ncp * sizeof(double),
                          hipMemcpyDeviceToHost, x->stream));
-  HIP_TRY(hipStreamSynchronize(x->stream));
+  if (wdpm_stream_sync(x, x->stream)) return 1;
   return 0;
 }
 
@@ -564,7 +596,7 @@ int wdpm_copy_rows(wdpm_ctx *dst, int32_t dst_row, wdpm_ctx *src, int32_t src_ro
   /* Rows that leave a context carry the last iteration's drain(): the receiver applies its own owed drain() only where the
    * outlet lies strictly inside ITS slab - not when the outlet's row is the slab's first or last row, and then the nine
    * cells must arrive zeroed (tests/test_rowblock.py::test_hip_outlet_on_the_last_row_of_the_neighbours_halo). */
-  if (ensure_drained(src)) return 1;
+  if (ensure_flushed(src)) return 1;   /* ... and the block's threshold flush, should the source still owe it to its raster */
   if (!src->ev_copy[0]) HIP_TRY(hipEventCreateWithFlags(&src->ev_copy[0], hipEventDisableTiming));
   HIP_TRY(hipEventRecord(src->ev_copy[0], src->stream));
   if (bind(dst)) return 1;
@@ -617,14 +649,14 @@ int wdpm_set_totaldrain(wdpm_ctx *x, double v) {
   if (bind(x) || ensure_drained(x)) return 1;
   x->h_pin[0] = v;
   HIP_TRY(hipMemcpyAsync(x->d_scal, x->h_pin, sizeof(double), hipMemcpyHostToDevice, x->stream));
-  HIP_TRY(hipStreamSynchronize(x->stream));
+  if (wdpm_stream_sync(x, x->stream)) return 1;
   return 0;
 }
 
 int wdpm_get_totaldrain(wdpm_ctx *x, double *v) {
   if (bind(x) || ensure_drained(x)) return 1;
   HIP_TRY(hipMemcpyAsync(x->h_pin, x->d_scal, sizeof(double), hipMemcpyDeviceToHost, x->stream));
-  HIP_TRY(hipStreamSynchronize(x->stream));
+  if (wdpm_stream_sync(x, x->stream)) return 1;
   *v = x->h_pin[0];
   return 0;
 }
@@ -865,7 +897,7 @@ int wdpm_max_diff(wdpm_ctx *x, int32_t row_lo, int32_t row_hi, double *out) {
     HIP_TRY(hipMemcpyAsync(x->h_active, x->d_active, sizeof(unsigned), hipMemcpyDeviceToHost, x->stream));
     HIP_TRY(hipMemsetAsync(x->d_active, 0, sizeof(unsigned), x->stream));
   }
-  HIP_TRY(hipStreamSynchronize(x->stream));
+  if (wdpm_stream_sync(x, x->stream)) return 1;
   *out = x->h_pin[0];
   if (look) {
     /* once per block: how many tiles worked?  Mostly dry -> short chunks from the next block on (and back) */
@@ -891,7 +923,7 @@ int wdpm_drain_stats(wdpm_ctx *x, double *diffdrain, double *final_sum) {
   if (bind(x) || ensure_drained(x)) return 1;
   if (diffdrain) {
     HIP_TRY(hipMemcpyAsync(x->h_pin, x->d_scal, 2 * sizeof(double), hipMemcpyDeviceToHost, x->stream));
-    HIP_TRY(hipStreamSynchronize(x->stream));
+    if (wdpm_stream_sync(x, x->stream)) return 1;
     *diffdrain = fabs(x->h_pin[0] - x->h_pin[1]);
   }
   if (final_sum) return wdpm_volume_partial(x, 0, x->g.rows, 0.0, final_sum);
@@ -927,7 +959,7 @@ int wdpm_volume_partial(wdpm_ctx *x, int32_t row_lo, int32_t row_hi, double star
   HIP_TRY(wdpm_launch_seqsum_a(w, dem, n, x->d_sum_approx, x->d_sum_flag, x->stream));
   HIP_TRY(hipMemcpyAsync(approx.data(), x->d_sum_approx, nchunks * sizeof(double), hipMemcpyDeviceToHost, x->stream));
   HIP_TRY(hipMemcpyAsync(flag.data(), x->d_sum_flag, nchunks * sizeof(unsigned), hipMemcpyDeviceToHost, x->stream));
-  HIP_TRY(hipStreamSynchronize(x->stream));
+  if (wdpm_stream_sync(x, x->stream)) return 1;
   const bool start_ok = start >= 0.0 && start < __builtin_inf();
   double prefix = start_ok ? start : 0.0;
   size_t eligible = 0;
@@ -948,7 +980,7 @@ int wdpm_volume_partial(wdpm_ctx *x, int32_t row_lo, int32_t row_hi, double star
     HIP_TRY(wdpm_launch_seqsum_b(w, dem, n, x->d_sum_k, x->d_sum_i, x->d_sum_flag, x->stream));
     HIP_TRY(hipMemcpyAsync(isum.data(), x->d_sum_i, nchunks * sizeof(long long), hipMemcpyDeviceToHost, x->stream));
     HIP_TRY(hipMemcpyAsync(flag.data(), x->d_sum_flag, nchunks * sizeof(unsigned), hipMemcpyDeviceToHost, x->stream));
-    HIP_TRY(hipStreamSynchronize(x->stream));
+    if (wdpm_stream_sync(x, x->stream)) return 1;
   }
   /* chain: a chunk's integer sum is used only if its assumption holds for the ACTUAL running sum */
   double s = start;
@@ -962,7 +994,7 @@ int wdpm_volume_partial(wdpm_ctx *x, int32_t row_lo, int32_t row_hi, double star
     tw.resize(len); td.resize(len);
     HIP_TRY(hipMemcpyAsync(tw.data(), w + off, len * sizeof(double), hipMemcpyDeviceToHost, x->stream));
     HIP_TRY(hipMemcpyAsync(td.data(), dem + off, len * sizeof(double), hipMemcpyDeviceToHost, x->stream));
-    HIP_TRY(hipStreamSynchronize(x->stream));
+    if (wdpm_stream_sync(x, x->stream)) return 1;
     for (size_t i = 0; i < len; i++)
       if (td[i] < __builtin_inf()) s += tw[i];                        /* the device DEM holds +inf for NODATA */
   }

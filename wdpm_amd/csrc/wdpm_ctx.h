@@ -80,6 +80,8 @@ struct wdpm_ctx {
   double ms;
   bool timing;                  /* record the event pairs at all (off until wdpm_timing_reset asks) */
   wdpm_comm *comm;              /* wdpm_comm_init_rank / wdpm_comm_init_all, or nullptr */
+  bool leak;                    /* a guarded RCCL call or a stream wait ran past its deadline: somebody may still be using this
+                                   context's stream and buffers, so wdpm_destroy frees none of them */
 };
 
 /* sets wdpm_last_error() of the calling thread and returns 1 */
@@ -87,5 +89,9 @@ int wdpm_fail(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
 void wdpm_comm_release(wdpm_ctx *x);   /* wdpm_destroy's hook */
 int wdpm_tiles_touch(wdpm_ctx *x, int row, int nrows);   /* rows of the current raster written from outside: dry-tile flags */
 int wdpm_apply_owed_drain(wdpm_ctx *x);   /* drain module: the last iteration's drain() if it has not been applied yet (before rows leave the context) */
+int wdpm_apply_owed_flush(wdpm_ctx *x);   /* that, and the block's threshold flush if the current raster is still owed it */
+/* hipStreamSynchronize - with a deadline when the context has a communicator (a transfer whose peer has died never completes):
+ * WDPM_SYNC_TIMEOUT_S, default 600 s; past it the communicator is aborted, the context is marked `leak` and 1 is returned */
+int wdpm_stream_sync(wdpm_ctx *x, hipStream_t s);
 
 #endif

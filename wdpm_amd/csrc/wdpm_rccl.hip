@@ -11,13 +11,28 @@
  * RCCL is bound at run time (dlopen of librccl.so.1): a single-GPU run needs no RCCL at all, and
  * inside a PyTorch process the copy PyTorch already mapped is the one that is used (same SONAME),
  * so there is one RCCL and one HIP runtime per process.
+ *
+ * Nothing here can wait for ever.  Communicator set-up and the FIRST transfer / all-gather of a communicator -
+ * the steps that map peer memory and open the links, and the only ones seen to block on a misconfigured fabric -
+ * run on a helper thread the caller waits for with a deadline (WDPM_RCCL_TIMEOUT_S, default 90 s); waits for the
+ * stream of a context that has a communicator poll with a deadline too (wdpm_stream_sync, WDPM_SYNC_TIMEOUT_S).
+ * A deadline that passes, or a rank of a group that fails, aborts the communicator (ncclCommAbort: the peers'
+ * queued receives end instead of waiting for rows that will never come) and the call returns an error; the caller
+ * then goes on with host-staged halos or exits non-zero - it never hangs.
  */
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <functional>
+#include <memory>
 #include <mutex>
+#include <thread>
+#include <vector>
 
 #include "wdpm_ctx.h"
 
@@ -29,6 +44,7 @@ struct RcclApi {
   ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;      /* optional: CommDestroy stands in */
   ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
@@ -74,12 +90,48 @@ void load_rccl() {
   SYM(GetErrorString, "ncclGetErrorString");
   SYM(GetVersion, "ncclGetVersion");
 #undef SYM
+  *(void **)(&g_api.CommAbort) = dlsym(g_api.handle, "ncclCommAbort");
 }
 
 int need_rccl() {
   std::call_once(g_once, load_rccl);
   if (!g_api.handle) return wdpm_fail("RCCL is not available: %s", g_api.why[0] ? g_api.why : "librccl.so.1 not found");
   return 0;
+}
+
+double env_seconds(const char *name, double dflt) {
+  const char *e = getenv(name);
+  const double v = e && *e ? atof(e) : dflt;
+  return v > 0 ? v : dflt;
+}
+
+/* fn() on a helper thread, waited for with a deadline.  0 / fn's status (its error text becomes the caller's), or 1
+ * with "... did not return" - the helper is then left behind (it is stuck inside RCCL; nothing it captured by value
+ * goes away, and the caller marks whatever it captured by pointer as not to be freed). */
+struct GuardState {
+  std::mutex mu;
+  std::condition_variable cv;
+  bool done = false;
+  int rc = 0;
+  char err[512] = "";
+};
+int run_guarded(const std::function<int()> &fn, const char *what, bool *timed_out = nullptr) {
+  const double seconds = env_seconds("WDPM_RCCL_TIMEOUT_S", 90.0);
+  auto st = std::make_shared<GuardState>();
+  std::thread([st, fn] {
+    const int rc = fn();
+    std::lock_guard<std::mutex> lk(st->mu);
+    st->rc = rc;
+    if (rc) snprintf(st->err, sizeof st->err, "%s", wdpm_last_error());
+    st->done = true;
+    st->cv.notify_all();
+  }).detach();
+  std::unique_lock<std::mutex> lk(st->mu);
+  const bool ok = st->cv.wait_for(lk, std::chrono::duration<double>(seconds), [&] { return st->done; });
+  if (timed_out) *timed_out = !ok;
+  if (!ok) return wdpm_fail("%s did not return within %.0f s (WDPM_RCCL_TIMEOUT_S)", what, seconds);
+  if (st->rc) wdpm_set_last_error(st->err);
+  return st->rc;
 }
 
 }  // namespace
@@ -89,6 +141,8 @@ struct wdpm_comm {
   int rank, nranks;
   double *d_mine, *d_all;   /* wdpm_comm_allgather staging: kGatherMax doubles, nranks * kGatherMax doubles */
   double *h_all;            /* pinned */
+  std::atomic<bool> dead;   /* aborted (a deadline passed, or a rank of the group failed): every call fails from now on */
+  bool exchanged, gathered; /* the first transfer / all-gather has come back: later ones are issued directly */
 };
 constexpr int kGatherMax = 8;
 
@@ -105,7 +159,7 @@ constexpr int kGatherMax = 8;
   } while (0)
 
 static int attach(wdpm_ctx *x, ncclComm_t comm, int rank, int nranks) {
-  wdpm_comm *c = new wdpm_comm{comm, rank, nranks, nullptr, nullptr, nullptr};
+  wdpm_comm *c = new wdpm_comm{comm, rank, nranks, nullptr, nullptr, nullptr, {false}, false, false};
   x->comm = c;
   HIP_TRY(hipSetDevice(x->p.device));
   HIP_TRY(hipMalloc(&c->d_mine, kGatherMax * sizeof(double)));
@@ -119,7 +173,8 @@ void wdpm_comm_release(wdpm_ctx *x) {
   wdpm_comm *c = x->comm;
   x->comm = nullptr;
   (void)hipSetDevice(x->p.device);
-  if (c->comm && g_api.handle) (void)g_api.CommDestroy(c->comm);
+  if (c->comm && g_api.handle && !c->dead.exchange(true)) (void)g_api.CommDestroy(c->comm);   /* an aborted one is gone already */
+  if (x->leak) return;          /* a helper thread stuck inside RCCL may still hold these */
   (void)hipFree(c->d_mine);
   (void)hipFree(c->d_all);
   if (c->h_all) (void)hipHostFree(c->h_all);
@@ -150,9 +205,17 @@ int wdpm_comm_init_rank(wdpm_ctx *x, int32_t nranks, int32_t rank, const void *i
   HIP_TRY(hipSetDevice(x->p.device));
   ncclUniqueId id;
   memcpy(&id, id128, sizeof id);
-  ncclComm_t comm;
-  NCCL_TRY(g_api.CommInitRank(&comm, nranks, id, rank));
-  return attach(x, comm, rank, nranks);
+  /* collective, and the one call of this path that has been seen to block for ever (fabric / IPC misconfiguration, a rank
+   * that never arrives): on a helper thread, with a deadline; the result lives in shared state the helper may outlive us with */
+  auto out = std::make_shared<ncclComm_t>(nullptr);
+  const int device = x->p.device;
+  const int rc = run_guarded([=]() -> int {
+    HIP_TRY(hipSetDevice(device));
+    NCCL_TRY(g_api.CommInitRank(out.get(), nranks, id, rank));
+    return 0;
+  }, "ncclCommInitRank");
+  if (rc) return rc;
+  return attach(x, *out, rank, nranks);
 }
 
 int wdpm_comm_init_all(wdpm_ctx **ctxs, int32_t n) {
@@ -166,19 +229,44 @@ int wdpm_comm_init_all(wdpm_ctx **ctxs, int32_t n) {
       if (dev[j] == dev[i] && !getenv("WDPM_RCCL_SHARED_DEVICE_OK"))   /* tests with a stand-in RCCL library set it */
         return wdpm_fail("wdpm_comm_init_all: device %d named twice (RCCL wants one rank per GPU)", dev[i]);
   }
-  ncclComm_t comm[64];
-  NCCL_TRY(g_api.CommInitAll(comm, n, dev));
+  auto comm = std::make_shared<std::vector<ncclComm_t>>((size_t)n, nullptr);
+  const std::vector<int> devs(dev, dev + n);
+  const int rc = run_guarded([=]() -> int {
+    NCCL_TRY(g_api.CommInitAll(comm->data(), n, devs.data()));
+    return 0;
+  }, "ncclCommInitAll");
+  if (rc) return rc;
   for (int i = 0; i < n; i++)
-    if (attach(ctxs[i], comm[i], i, n)) return 1;
+    if (attach(ctxs[i], (*comm)[i], i, n)) return 1;
   return 0;
 }
 
 int wdpm_comm_size(wdpm_ctx *x, int32_t *nranks, int32_t *rank) {
   if (!x || !x->comm) return wdpm_fail("wdpm_comm_size: the context has no communicator");
+  if (x->comm->dead) return wdpm_fail("wdpm_comm_size: the communicator was aborted");
   int n = 0;
   NCCL_TRY(g_api.CommCount(x->comm->comm, &n));   /* what RCCL itself says, not what we were told */
   if (nranks) *nranks = n;
   if (rank) *rank = x->comm->rank;
+  return 0;
+}
+
+/* End the communicator NOW: queued and running transfers of this rank end, the peers' matching ones fail instead of
+ * waiting (ncclCommAbort).  May be called from another thread than the one driving the context (a failing rank of a
+ * group aborts everybody's).  The context keeps working without halos; every later wdpm_comm_* call on it fails. */
+int wdpm_comm_abort(wdpm_ctx *x) {
+  if (!x || !x->comm) return 0;
+  wdpm_comm *c = x->comm;
+  if (c->dead.exchange(true)) return 0;
+  if (!g_api.handle || !c->comm) return 0;
+  const ncclComm_t comm = c->comm;
+  const int device = x->p.device;
+  /* the abort itself is given a deadline too: it has to talk to a runtime that is, by assumption, in trouble */
+  (void)run_guarded([=]() -> int {
+    (void)hipSetDevice(device);
+    (void)(g_api.CommAbort ? g_api.CommAbort(comm) : g_api.CommDestroy(comm));
+    return 0;
+  }, "ncclCommAbort");
   return 0;
 }
 
@@ -191,6 +279,7 @@ int wdpm_comm_exchange(wdpm_ctx *x, int32_t nsend, const wdpm_halo_op *sends, in
   if (!x || !x->comm) return wdpm_fail("wdpm_comm_exchange: the context has no communicator");
   if (nsend < 0 || nrecv < 0 || (nsend && !sends) || (nrecv && !recvs)) return wdpm_fail("wdpm_comm_exchange: bad argument");
   wdpm_comm *c = x->comm;
+  if (c->dead) return wdpm_fail("wdpm_comm_exchange: the communicator was aborted");
   for (int pass = 0; pass < 2; pass++) {
     const wdpm_halo_op *ops = pass ? recvs : sends;
     for (int i = 0; i < (pass ? nrecv : nsend); i++)
@@ -199,20 +288,33 @@ int wdpm_comm_exchange(wdpm_ctx *x, int32_t nsend, const wdpm_halo_op *sends, in
         return wdpm_fail("wdpm_comm_exchange: bad row range or peer");
   }
   HIP_TRY(hipSetDevice(x->p.device));
-  if (nsend > 0 && wdpm_apply_owed_drain(x)) return 1;   /* rows that leave carry the last iteration's drain() (see wdpm_copy_rows) */
+  /* rows that leave carry the last iteration's drain() and the block's threshold flush if it is still owed (see wdpm_copy_rows) */
+  if (nsend > 0 && wdpm_apply_owed_flush(x)) return 1;
   for (int i = 0; i < nrecv; i++)
     if (wdpm_tiles_touch(x, recvs[i].row, recvs[i].nrows)) return 1;   /* received rows: those tiles are no longer known dry */
   double *w = x->d_w[x->cur];
   const size_t ncp = (size_t)x->g.ncp;
-  NCCL_TRY(g_api.GroupStart());
-  for (int i = 0; i < nsend; i++)
-    if (sends[i].nrows > 0)
-      NCCL_TRY(g_api.Send(w + (size_t)sends[i].row * ncp, (size_t)sends[i].nrows * ncp, ncclDouble, sends[i].peer, c->comm, x->stream));
-  for (int i = 0; i < nrecv; i++)
-    if (recvs[i].nrows > 0)
-      NCCL_TRY(g_api.Recv(w + (size_t)recvs[i].row * ncp, (size_t)recvs[i].nrows * ncp, ncclDouble, recvs[i].peer, c->comm, x->stream));
-  NCCL_TRY(g_api.GroupEnd());
-  return 0;
+  const std::vector<wdpm_halo_op> vs(sends, sends + nsend), vr(recvs, recvs + nrecv);
+  const ncclComm_t comm = c->comm;
+  const hipStream_t stream = x->stream;
+  const int device = x->p.device;
+  auto group = [=]() -> int {
+    HIP_TRY(hipSetDevice(device));
+    NCCL_TRY(g_api.GroupStart());
+    for (const wdpm_halo_op &o : vs)
+      if (o.nrows > 0) NCCL_TRY(g_api.Send(w + (size_t)o.row * ncp, (size_t)o.nrows * ncp, ncclDouble, o.peer, comm, stream));
+    for (const wdpm_halo_op &o : vr)
+      if (o.nrows > 0) NCCL_TRY(g_api.Recv(w + (size_t)o.row * ncp, (size_t)o.nrows * ncp, ncclDouble, o.peer, comm, stream));
+    NCCL_TRY(g_api.GroupEnd());
+    return 0;
+  };
+  if (c->exchanged) return group();
+  /* the first transfer of a communicator sets up the peer mappings and the links: with a deadline (see the head of this file) */
+  bool timed_out = false;
+  const int rc = run_guarded(group, "the first RCCL halo transfer", &timed_out);
+  if (timed_out) { x->leak = true; (void)wdpm_comm_abort(x); }   /* the helper still holds this context's buffers and stream */
+  if (rc == 0) c->exchanged = true;
+  return rc;
 }
 
 /* all[r * n + i] = mine[i] of rank r (n <= 8), on every rank; synchronous (block-loop scalars:
@@ -221,13 +323,31 @@ int wdpm_comm_allgather(wdpm_ctx *x, const double *mine, int32_t n, double *all)
   if (!x || !x->comm) return wdpm_fail("wdpm_comm_allgather: the context has no communicator");
   if (!mine || !all || n < 1 || n > kGatherMax) return wdpm_fail("wdpm_comm_allgather: bad argument");
   wdpm_comm *c = x->comm;
+  if (c->dead) return wdpm_fail("wdpm_comm_allgather: the communicator was aborted");
   HIP_TRY(hipSetDevice(x->p.device));
   double *h_mine = c->h_all + (size_t)c->nranks * kGatherMax;
   memcpy(h_mine, mine, n * sizeof(double));
   HIP_TRY(hipMemcpyAsync(c->d_mine, h_mine, n * sizeof(double), hipMemcpyHostToDevice, x->stream));
-  NCCL_TRY(g_api.AllGather(c->d_mine, c->d_all, (size_t)n, ncclDouble, c->comm, x->stream));
+  const ncclComm_t comm = c->comm;
+  const hipStream_t stream = x->stream;
+  const int device = x->p.device;
+  double *d_mine = c->d_mine, *d_all = c->d_all;
+  auto gather = [=]() -> int {
+    HIP_TRY(hipSetDevice(device));
+    NCCL_TRY(g_api.AllGather(d_mine, d_all, (size_t)n, ncclDouble, comm, stream));
+    return 0;
+  };
+  if (c->gathered) {
+    if (gather()) return 1;
+  } else {
+    bool timed_out = false;
+    const int rc = run_guarded(gather, "the first RCCL all-gather", &timed_out);
+    if (timed_out) { x->leak = true; (void)wdpm_comm_abort(x); }
+    if (rc) return rc;
+    c->gathered = true;
+  }
   HIP_TRY(hipMemcpyAsync(c->h_all, c->d_all, (size_t)c->nranks * n * sizeof(double), hipMemcpyDeviceToHost, x->stream));
-  HIP_TRY(hipStreamSynchronize(x->stream));
+  if (wdpm_stream_sync(x, x->stream)) return 1;       /* with a deadline: a peer that died must not hang this rank */
   memcpy(all, c->h_all, (size_t)c->nranks * n * sizeof(double));
   return 0;
 }

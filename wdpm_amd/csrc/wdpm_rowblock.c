@@ -123,12 +123,18 @@ struct wdpm_group {
 
 static void grp_fail(struct wdpm_group *g, const char *msg) {
   pthread_mutex_lock(&g->mu);
-  if (!g->failed) {
+  const int first = !g->failed;
+  if (first) {
     g->failed = 1;
     snprintf(g->err, sizeof g->err, "%s", msg && *msg ? msg : "a rank of the group failed");
   }
   pthread_cond_broadcast(&g->cv_bar);
   pthread_mutex_unlock(&g->mu);
+  /* the other ranks may have halo receives queued whose sender - this rank - will never post: end every communicator,
+   * so that their streams drain and their waits return instead of hanging (the host barriers were released above) */
+  if (first && g->halo == WDPM_HALO_RCCL)
+    for (int i = 0; i < g->n; i++)
+      if (g->r[i]) wdpm_comm_abort(g->r[i]->c);
 }
 
 /* all rank threads meet; released early (returning 1) once any rank has failed */

@@ -196,6 +196,11 @@ class RowBlockSolver:
         except Exception:
             pass
 
+    def abort_comm(self):
+        """wdpm_comm_abort: end this rank's communicator now (queued transfers end, the peers' fail instead of waiting)"""
+        if self._h:
+            self.lib.dll.wdpm_comm_abort(self.ctx._h)
+
     def rccl_ranks(self) -> int | None:
         """communicator size as RCCL itself reports it (ncclCommCount), None without RCCL halos"""
         if self.halo_kind != HALO_RCCL:
