@@ -142,7 +142,8 @@ def test_default_schedule_over_the_standin_rccl_equals_the_reference(hip):
     from conftest import ROOT
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "mock_rccl")], stdout=subprocess.DEVNULL)
     env = dict(os.environ, WDPM_RCCL_LIB=os.path.join(ROOT, "tests", "mock_rccl", "libmock_rccl.so"), WDPM_HALO="rccl",
-               WDPM_RCCL_SHARED_DEVICE_OK="1", WDPM_FULL_SIZE_WORKER="1")
+               WDPM_RCCL_SHARED_DEVICE_OK="1", WDPM_FULL_SIZE_WORKER="1",
+               PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "tests"), os.environ.get("PYTHONPATH", "")]))
     p = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
     assert "FULL_SIZE_RCCL_OK add" in p.stdout and "FULL_SIZE_RCCL_OK drain" in p.stdout, p.stdout

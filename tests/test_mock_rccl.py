@@ -109,14 +109,20 @@ def test_bench_ranks_over_mock_rccl_processes(proc_env, one_rank_line):
     assert "degraded" not in d and "2.99.99" in c["rccl"] and c["exchange_every"] == 4
     assert c["max_diff_m"] == one_rank_line["config"]["max_diff_m"]
     assert "sends over" in err                              # the stand-in says which wire ran (IPC-mapped memory or a file)
+    wire = sorted({ln.split("sends over ")[1] for ln in err.splitlines() if "sends over " in ln})
+    print("stand-in RCCL wire between rank processes:", wire)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "mock_rccl_wire.txt"), "w") as f:
+        f.write("\n".join(wire) + "\n")
 
 
-def test_bench_eight_ranks_over_mock_rccl_processes(proc_env):
-    """the driver's N = 8 command shape on the one GPU of this box (5 ranks: the pool allows six GPU processes)"""
-    d5, _ = bench_line(proc_env, "--gpus", "5", "--size", "4096", "--steps", "20", "--warmup", "5")
+def test_bench_four_ranks_over_mock_rccl_processes(proc_env):
+    """the driver's N = 8 command shape on the one GPU of this box (4 ranks: the pool allows six processes on the GPU at
+    once, and the test runner and the launcher count)"""
+    d4, _ = bench_line(proc_env, "--gpus", "4", "--size", "4096", "--steps", "20", "--warmup", "5")
     d1, _ = bench_line(dict(os.environ), "--size", "4096", "--steps", "20", "--warmup", "5")
-    assert d5["n_gpus"] == 5 and d5["config"]["halo"] == "rccl" and d5["config"]["rccl_ranks"] == 5 and "degraded" not in d5
-    assert d5["config"]["max_diff_m"] == d1["config"]["max_diff_m"]
+    assert d4["n_gpus"] == 4 and d4["config"]["halo"] == "rccl" and d4["config"]["rccl_ranks"] == 4 and "degraded" not in d4
+    assert d4["config"]["max_diff_m"] == d1["config"]["max_diff_m"]
 
 
 def test_bench_goes_on_with_host_halos_when_communicator_setup_hangs(proc_env, one_rank_line):
