@@ -243,17 +243,23 @@ __device__ __forceinline__ void stage_impl(double (&W)[7][3], const double (&D)[
  * row is wave-uniform (computed on the scalar unit), so all other steps run the plain neighbour step -
  * as ONE basic block of three stages, which lets the scheduler overlap the stages' tails and heads
  * (a test per stage cut the step into three blocks). */
-template <int MODULE, bool SZ_SAFE>
+/* NSTAGES < 3: the first two steps of a chunk.  Step 0 holds real rows only in slots 4..6: its oi = 2 block has its centre
+ * on an empty slot (dem = +inf: nothing moves), its oi = 3 block lies on empty slots altogether.  Step 1's oi = 3 block
+ * (rows A-1 .. A+1, centre row A) touches rows A and A+1 only, after the last pass that reads them in this iteration, and
+ * those rows are never stored (a chunk stores from row A+2; for A = 0 the centre row is the raster's border or a slab's
+ * first halo row, which is wrong from the first iteration after a refresh on anyway): dead work.  Leaving those three stage
+ * executions out saves 3 of 3 (H/3 + 2): 9 % of a 27-row chunk, 5.6 % at 48 rows, 0.4 % at 780. */
+template <int MODULE, bool SZ_SAFE, int NSTAGES = 3>
 __device__ __forceinline__ void three_stages(double (&W)[7][3], const double (&D)[7][3], const int rbase,
                                              const int drain_row, const bool (&cdr)[5], DrainState &ds) {
   if (MODULE == 2 && drain_row >= rbase && drain_row <= rbase + 6) {           // wave-uniform, rare
     stage_impl<MODULE, SZ_SAFE, 4, true>(W, D, rbase + 4, drain_row, cdr, ds);   // oi = 1 on rows 3n   .. 3n+2
-    stage_impl<MODULE, SZ_SAFE, 2, true>(W, D, rbase + 2, drain_row, cdr, ds);   // oi = 2 on rows 3n-2 .. 3n
-    stage_impl<MODULE, SZ_SAFE, 0, true>(W, D, rbase + 0, drain_row, cdr, ds);   // oi = 3 on rows 3n-4 .. 3n-2
+    if (NSTAGES >= 2) stage_impl<MODULE, SZ_SAFE, 2, true>(W, D, rbase + 2, drain_row, cdr, ds);   // oi = 2 on rows 3n-2 .. 3n
+    if (NSTAGES >= 3) stage_impl<MODULE, SZ_SAFE, 0, true>(W, D, rbase + 0, drain_row, cdr, ds);   // oi = 3 on rows 3n-4 .. 3n-2
   } else {
     stage_impl<MODULE, SZ_SAFE, 4, false>(W, D, rbase + 4, drain_row, cdr, ds);
-    stage_impl<MODULE, SZ_SAFE, 2, false>(W, D, rbase + 2, drain_row, cdr, ds);
-    stage_impl<MODULE, SZ_SAFE, 0, false>(W, D, rbase + 0, drain_row, cdr, ds);
+    if (NSTAGES >= 2) stage_impl<MODULE, SZ_SAFE, 2, false>(W, D, rbase + 2, drain_row, cdr, ds);
+    if (NSTAGES >= 3) stage_impl<MODULE, SZ_SAFE, 0, false>(W, D, rbase + 0, drain_row, cdr, ds);
   }
 }
 
@@ -494,7 +500,8 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
       __builtin_amdgcn_wave_barrier();
     };
 
-    auto step = [&](const int n, Prefetched &P) {
+    auto step = [&](const int n, Prefetched &P, auto nstages_tag) {
+      constexpr int NSTAGES = decltype(nstages_tag)::value;
       read_staged();
       // consume the prefetched rows into window slots 4..6; the device DEM already holds +inf for
       // NODATA cells, so only edge waves have anything to mask (outside the slab: dem=+inf, w=0)
@@ -535,7 +542,7 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
 
       const int rbase = A + 3 * n - 4;                 // slab row of window slot 0
 #ifndef WDPM_ABLATE_COMPUTE                            /* timing experiments only: memory pattern alone */
-      three_stages<MODULE, SZ_SAFE>(W, D, rbase, g.dr, cdr, ds);
+      three_stages<MODULE, SZ_SAFE, NSTAGES>(W, D, rbase, g.dr, cdr, ds);
 #else
 #pragma unroll
       for (int j = 0; j < 3; j++) W[0][j] += D[0][j] + D[1][j] + D[2][j];   // keep the dem loads alive
@@ -589,7 +596,17 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
     Prefetched P;
     prefetch(P, A);
     WDPM_WAIT_ROWS(0);
-    for (int n = 0; n < nsteps; n++) step(n, P);
+    if constexpr (MODULE == 2) {
+      // drain is bound by instruction issue (16 instructions per neighbour step): the dead stages of a chunk's first two
+      // steps are left out (1-3 % at 4096^2, 5 % on the 1055-row slabs of 8 GPUs).  Add / subtract keep them: those
+      // launches are bound by the memory system, the arithmetic of the first steps paces the waves' first requests, and
+      // without it 4096^2 ran 4 % SLOWER (profiles/r03/warmup_stages_ab.txt)
+      step(0, P, std::integral_constant<int, 1>{});      // nsteps >= 3: H >= 3
+      step(1, P, std::integral_constant<int, 2>{});
+      for (int n = 2; n < nsteps; n++) step(n, P, std::integral_constant<int, 3>{});
+    } else {
+      for (int n = 0; n < nsteps; n++) step(n, P, std::integral_constant<int, 3>{});
+    }
     read_staged();
     write_staged(A + 3 * (nsteps - 1) - 4);    // the last step's rows
 #undef WDPM_WAIT_ROWS
