@@ -305,7 +305,7 @@ def main():
     ap.add_argument("--steps", type=int, default=1000)   # one block of the reference loop
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--size", type=int, default=16384)
-    ap.add_argument("--exchange-every", type=int, default=int(os.environ.get("WDPM_EXCHANGE_EVERY", "4")))
+    ap.add_argument("--exchange-every", type=int, default=int(os.environ.get("WDPM_EXCHANGE_EVERY", "8")))
     ap.add_argument("--kernel", choices=["auto", "pass", "fused"], default="auto")
     ap.add_argument("--driver", choices=["ranks", "group"], default="ranks",
                     help="ranks = one process per GPU (torch.distributed.run); group = all ranks in this process, one "
@@ -552,11 +552,9 @@ def main():
         pmc = measured_counters(n, ranks_used, args.kernel, dem32) if args.module == "add" else {}
         traffic = pmc.get("traffic")
         hbm_real = traffic / (iter_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic and iter_ms > 0 else None
-        # VALU issue share measured with the counters, rescaled to THIS run's kernel time (the instruction count per launch
-        # is a property of the binary; the time is not)
+        # VALU issue share as the counters gave it: a share of the kernel's cycles (instructions per launch are a property
+        # of the binary, and the share does not depend on the clock of the profiled pass)
         valu = pmc.get("valu_issue_frac")
-        if valu and pmc.get("kernel_ms_at_collection") and iter_ms > 0:
-            valu = valu * pmc["kernel_ms_at_collection"] / iter_ms
         bound = "hbm"
         if valu and valu > (hbm_real if hbm_real is not None else moved / (iter_ms * 1e-3) / 1e9 / HBM_PEAK_GBS):
             bound = "valu-issue (fp64; no MFMA in this path) ahead of hbm"

@@ -8,9 +8,10 @@ volume sum.  Bit-exact is the bar: every comparison below is on hashes of the fp
 
 What is pinned, exactly: one context at 2 / 20 iterations (both kernels, DEM codes on and off, another chunk
 height); row blocks at 16384^2 with exchange interval k = 1 (4 slabs) and k = 2 (8 slabs) over 2 iterations, and
-with the DEFAULT k = 4 on 8 slabs over 9 iterations - two halo refreshes and a ninth iteration that consumes the
-second - once over peer copies and once over the stand-in RCCL (tests/mock_rccl); drain at 8192^2 on 1 and 3 slabs
-(k = 2, 5 iterations) and on 8 slabs at the default k = 4 over 9 iterations, again over both transports."""
+with k = 4 AND the default k = 8 on 8 slabs over 9 iterations - halo refreshes after iterations 4 and 8, or after 8,
+and a ninth iteration that runs on the refreshed halos - once over peer copies and once over the stand-in RCCL
+(tests/mock_rccl); drain at 8192^2 on 1 and 3 slabs (k = 2, 5 iterations) and on 8 slabs at k = 4 and the default
+k = 8 over 9 iterations, again over both transports."""
 import hashlib
 import json
 import os
@@ -111,20 +112,22 @@ def test_row_blocks_at_16384_equal_the_reference(hip, golden, devices, k):
 
 
 @pytest.mark.gpu
-def test_row_blocks_at_the_default_exchange_interval_equal_the_reference(hip, golden):
-    """config 4 as bench.py and WDPMCL run it by default: 8 row blocks, halos refreshed every FOUR iterations; nine
-    iterations, so that the ninth runs on halos refreshed under that schedule (reference loop: WDPMCL.c:1094-1106)"""
+@pytest.mark.parametrize("every", [None, 4])
+def test_row_blocks_at_the_default_exchange_interval_equal_the_reference(hip, golden, every):
+    """config 4 as bench.py and WDPMCL run it by default: 8 row blocks, halos refreshed every EIGHT iterations (round 3:
+    179 against 187 us per iteration on an 8-GPU slab, profiles/r03/scale_projection.txt; and every four, the earlier
+    default); nine iterations, so that the ninth runs on halos refreshed under that schedule (WDPMCL.c:1094-1106)"""
     from wdpm_amd.rowblock import Group
     z, idx = golden
     meta = idx["cfg4_add_16384_i9"]
     n = meta["n"]
     bd, bw = inputs(hip, n)
-    with Group(hip, "add", n, n, MISS, [0] * 8) as g:              # exchange_every: the default
+    with Group(hip, "add", n, n, MISS, [0] * 8, **(dict(exchange_every=every) if every else {})) as g:
         assert g.size == 8
         import ctypes as C
         k = C.c_int32()
         hip.check(hip.dll.wdpm_rank_info(hip.dll.wdpm_group_rank(g._h, 0), None, C.byref(k), None))
-        assert k.value == 4
+        assert k.value == (every or 8)
         g.upload(bd, bw)
         md = g.run_block(meta["add_iters"], THRES)
         w = g.download_water()
@@ -134,7 +137,7 @@ def test_row_blocks_at_the_default_exchange_interval_equal_the_reference(hip, go
 
 @pytest.mark.gpu
 def test_default_schedule_over_the_standin_rccl_equals_the_reference(hip):
-    """the same two full-size jobs (add 16384^2 x9, drain 8192^2 x9; 8 slabs, k = 4) with the halos going through the
+    """the same two full-size jobs (add 16384^2 x9, drain 8192^2 x9; 8 slabs, default k = 8) with the halos going through the
     library's RCCL path (wdpm_comm_exchange on each rank's stream; the wire is tests/mock_rccl) - in a child process,
     because the stand-in has to be bound before the library looks for RCCL"""
     import subprocess
@@ -176,10 +179,11 @@ def drain_job(hip, z, meta, devices, k):
 
 
 @pytest.mark.gpu
-def test_drain_on_8_slabs_at_the_default_interval_equals_the_reference(hip, golden):
-    """config 5's decomposition: 8 row blocks, default exchange interval, nine drain iterations (WDPMCL.c:1076-1093)"""
+@pytest.mark.parametrize("every", [None, 4])
+def test_drain_on_8_slabs_at_the_default_interval_equals_the_reference(hip, golden, every):
+    """config 5's decomposition: 8 row blocks, default exchange interval (8) and 4, nine drain iterations (WDPMCL.c:1076-1093)"""
     z, idx = golden
-    drain_job(hip, z, idx["cfg5_drain_8192_a3_d9"], [0] * 8, None)
+    drain_job(hip, z, idx["cfg5_drain_8192_a3_d9"], [0] * 8, every)
 
 
 @pytest.mark.gpu

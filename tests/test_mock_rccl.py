@@ -106,7 +106,7 @@ def test_bench_ranks_over_mock_rccl_processes(proc_env, one_rank_line):
     d, err = bench_line(proc_env, "--gpus", "2", "--size", "2048", "--steps", "13", "--warmup", "3")
     c = d["config"]
     assert d["n_gpus"] == 2 and c["halo"] == "rccl" and c["rccl_ranks"] == 2 and c["dist_backend"] == "gloo", c
-    assert "degraded" not in d and "2.99.99" in c["rccl"] and c["exchange_every"] == 4
+    assert "degraded" not in d and "2.99.99" in c["rccl"] and c["exchange_every"] == 8
     assert c["max_diff_m"] == one_rank_line["config"]["max_diff_m"]
     assert "sends over" in err                              # the stand-in says which wire ran (IPC-mapped memory or a file)
     wire = sorted({ln.split("sends over ")[1] for ln in err.splitlines() if "sends over " in ln})

@@ -21,7 +21,7 @@
  *     as the reference's src/cmap_black.sh does for the GUI's PNG button (<output>.png; the .aux.xml is removed).
  *   - WDPM_DEVICE=<n> selects the HIP device (default 0).  WDPM_GPUS=<N> spreads the raster over
  *     devices 0..N-1 by row blocks (WDPM_DEVICES=a,b,c names them explicitly), one host thread per device,
- *     exchanging halo rows every WDPM_EXCHANGE_EVERY iterations (default 4) by RCCL send/recv
+ *     exchanging halo rows every WDPM_EXCHANGE_EVERY iterations (default 8) by RCCL send/recv
  *     (WDPM_HALO=peer: peer copies); results do not depend on N.
  */
 #include <ctype.h>
@@ -709,7 +709,7 @@ int main(int argc, char **argv) {
   p.draincol = cfg.module == WDPM_DRAIN ? (host_drain_search ? st.draincol : -1) : 0;
   int32_t devices[64];
   const int ndev_asked = split_for_size(devices, device_list(devices, 64), 64, ((double)p.nrows + 2) * ((double)p.ncols + 2));
-  const int every = getenv("WDPM_EXCHANGE_EVERY") ? atoi(getenv("WDPM_EXCHANGE_EVERY")) : 4;
+  const int every = getenv("WDPM_EXCHANGE_EVERY") ? atoi(getenv("WDPM_EXCHANGE_EVERY")) : 8;
   wdpm_setup su;
   memset(&su, 0, sizeof su);
   if (st.apply_module_water) {

@@ -138,7 +138,7 @@ class RowBlockSolver:
     (needs a HostTransport) or None = rccl when no transport is given."""
 
     def __init__(self, lib: Lib, module, nrows: int, ncols: int, missingvalue: float, rank: int = 0,
-                 nranks: int = 1, exchange_every: int = 4, transport: HostTransport | None = None, dist=None,
+                 nranks: int = 1, exchange_every: int = 8, transport: HostTransport | None = None, dist=None,
                  drainrow: int = 0, draincol: int = 0, device: int = 0, kernel: int = 0, chunk_rows: int = 0,
                  halo: str | None = None):
         self.lib, self.rank, self.nranks, self.dist = lib, rank, nranks, dist
@@ -265,7 +265,7 @@ class Group:
     """wdpm_group_*: the ranks of ONE process, one host thread per device — what the WDPMCL drop-in
     uses with WDPM_GPUS=N.  devices may repeat (several slabs on one GPU: peer-copy halos)."""
 
-    def __init__(self, lib: Lib, module, nrows: int, ncols: int, missingvalue: float, devices, exchange_every: int = 4,
+    def __init__(self, lib: Lib, module, nrows: int, ncols: int, missingvalue: float, devices, exchange_every: int = 8,
                  drainrow: int = 0, draincol: int = 0, kernel: int = 0, chunk_rows: int = 0):
         self.lib = lib
         m = MODULES[module] if isinstance(module, str) else module
