@@ -107,7 +107,7 @@ class SharedDem:
                 pass
 
 
-def measured_counters(n, world, kernel, dem):
+def measured_counters(n, world, kernel, dem32):
     """Counter evidence for the dominant kernel from the committed rocprofv3 PMC passes (separate
     --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE runs of this same command,
     gfx950 x2 FETCH correction, calibrated on kernels of known byte count: profiles/).  Only for the
@@ -120,7 +120,7 @@ def measured_counters(n, world, kernel, dem):
         with open(path) as f:
             t = json.load(f)
         if t["size"] == n and t["n_gpus"] == world and kernel in ("auto", "fused"):
-            e = t[{2: "dem16", 1: "dem32", 0: "fp64_dem"}[dem]]
+            e = t["dem32" if dem32 else "fp64_dem"]
             return {"traffic": e["hbm_bytes_per_launch"], "valu_issue_frac": e.get("valu_issue_frac"),
                     "kernel_ms_at_collection": e.get("kernel_ms"), "source": e.get("source")}
     except (OSError, KeyError, ValueError):
@@ -427,8 +427,6 @@ def main():
         v = C.c_int64()
         lib.check(lib.dll.wdpm_get_option(ctx0, wdpm_amd.OPT_DEM32, C.byref(v)))
         dem32 = bool(v.value) and args.module == "add"
-        lib.check(lib.dll.wdpm_get_option(ctx0, wdpm_amd.capi.OPT_DEM16, C.byref(v)))
-        dem16 = dem32 and bool(v.value)
         sl = wdpm_amd.capi.SlabStruct()
         lib.check(lib.dll.wdpm_rank_slab(lib.dll.wdpm_group_rank(grp._h, 0), 0, C.byref(sl)))
         own_rows0 = sl.own_hi - sl.own_lo + 1 if ranks_used > 1 else n
@@ -534,7 +532,6 @@ def main():
         launches, kernel_ms = solver.ctx.timing()
         steady_launches, steady_ms = solver.ctx.timing_steady()
         dem32 = bool(solver.ctx.get_option(wdpm_amd.OPT_DEM32)) and args.module == "add"
-        dem16 = dem32 and bool(solver.ctx.get_option(wdpm_amd.capi.OPT_DEM16))
         own_rows0 = solver.slab.own_hi - solver.slab.own_lo + 1 if world > 1 else n
         decomposition = f"row-block x{world}, one process per GPU" if world > 1 else "single GPU"
         enqueue_us = refresh_us = None
@@ -551,10 +548,8 @@ def main():
         all_ms = kernel_ms / max(args.steps, 1)
         iter_ms = steady_ms / steady_launches if steady_launches > 0 else all_ms
         achieved = ALGO_BYTES_PER_CELL_UPDATE * own_cells / (iter_ms * 1e-3) / 1e9 if iter_ms > 0 else 0.0
-        # what the kernel really streams: the DEM as 2-byte offsets + one 4-byte base per 48 cells, as 4-byte codes, or as fp64
-        dem_bytes = 2.0 + 4.0 / 48.0 if dem16 else (4.0 if dem32 else 8.0)
-        moved = (16.0 + dem_bytes) * own_cells
-        pmc = measured_counters(n, ranks_used, args.kernel, 2 if dem16 else (1 if dem32 else 0)) if args.module == "add" else {}
+        moved = (20.0 if dem32 else 24.0) * own_cells    # what the kernel really streams (DEM as 4-byte codes or fp64)
+        pmc = measured_counters(n, ranks_used, args.kernel, dem32) if args.module == "add" else {}
         traffic = pmc.get("traffic")
         hbm_real = traffic / (iter_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic and iter_ms > 0 else None
         # VALU issue share as the counters gave it: a share of the kernel's cycles (instructions per launch are a property
@@ -593,10 +588,8 @@ def main():
                          # share of the kernel's cycles in which a SIMD issues a VALU instruction: the OTHER ceiling
                          "valu_issue_frac": valu,
                          "counters_source": ("profiles/traffic.json <- " + str(pmc.get("source"))) if pmc else None,
-                         "dem": ("16-bit offsets from one 32-bit base per 48 cells of a row, an exact identity with the 32-bit codes "
-                                 "verified lossless on upload (18.1 B of HBM traffic per cell-update)") if dem16 else
-                                ("32-bit codes, verified lossless on upload (20 B of HBM traffic per cell-update)" if dem32
-                                 else "fp64 (24 B of HBM traffic per cell-update)"),
+                         "dem": "32-bit codes, verified lossless on upload (20 B of HBM traffic per cell-update)" if dem32
+                                else "fp64 (24 B of HBM traffic per cell-update)",
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_CELL_UPDATE * own_cells,
                          "moved_bytes_per_launch": moved,
                          "moved_frac": moved / (iter_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if iter_ms > 0 else 0.0,

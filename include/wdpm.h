@@ -320,10 +320,6 @@ int  wdpm_group_enqueue_stats(wdpm_group *grp, double *seconds, double *exchange
  *   setting 1 is honoured only for a DEM that passed the check; the kernel then uses the codes on
  *   launches large enough for them to pay (>= 4096^2 or so), setting 2 on launches of any size.  WDPM_DEM32=0 in the environment
  *   disables the encoding altogether, WDPM_DEM32=2 makes 2 the default.  The CPU restatement reports 0.
- * WDPM_OPT_DEM16 (get/set; round 3): 1 = those codes are streamed as 16-bit offsets from one 32-bit base per 48 columns of a
- *   row (2.08 bytes per cell-update instead of 4).  Switched on by wdpm_upload, on top of WDPM_OPT_DEM32, when no such group of
- *   cells spans more than 65 534 quanta (6.5 m of relief at a DEM resolution of 1e-4 m, 655 m at 1e-2 m) - an exact integer
- *   identity with the 32-bit codes, so results are identical again.  WDPM_DEM16=0 in the environment disables it.
  * WDPM_OPT_TILES (get/set): 1 (default; WDPM_TILES=0 in the environment: 0) = dry-tile skipping.  The reference
  *   skips dry centres cell by cell (WDPMCL.c:1099); the iteration kernel keeps, per water raster, one flag per
  *   tile (the output block of one wave) saying "all +0.0", and a wave whose tile and eight neighbours are flagged
@@ -335,7 +331,7 @@ int  wdpm_group_enqueue_stats(wdpm_group *grp, double *seconds, double *exchange
  *   carry n KiB guard bands; this counts guard bytes that were overwritten (0 = no kernel wrote outside its buffer; always 0
  *   without the variable).  A debugging aid: the GPU pool has no address sanitizer. */
 enum { WDPM_OPT_SIGNED_ZERO_SAFE = 1, WDPM_OPT_DEM32 = 2, WDPM_OPT_TILES = 3, WDPM_OPT_TILES_SEEN = 4,
-       WDPM_OPT_TILES_WORKED = 5, WDPM_OPT_SPARSE = 6, WDPM_OPT_GUARD_BAD = 7, WDPM_OPT_DEM16 = 8 };
+       WDPM_OPT_TILES_WORKED = 5, WDPM_OPT_SPARSE = 6, WDPM_OPT_GUARD_BAD = 7 };
 int wdpm_get_option(wdpm_ctx *ctx, int32_t key, int64_t *value);
 int wdpm_set_option(wdpm_ctx *ctx, int32_t key, int64_t value);
 

@@ -54,10 +54,10 @@ def test_counter_evidence_is_quoted_for_the_headline_configuration():
     spec = importlib.util.spec_from_file_location("bench_counters", os.path.join(ROOT, "bench.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    c = mod.measured_counters(16384, 1, "auto", 1)
+    c = mod.measured_counters(16384, 1, "auto", True)
     assert 0.8 * 20 * 16384 ** 2 < c["traffic"] < 24 * 16384 ** 2 and 0.5 < c["valu_issue_frac"] < 1.0 and c["kernel_ms_at_collection"] > 0
     assert os.path.exists(os.path.join(ROOT, c["source"].split(" ")[0]))
-    assert mod.measured_counters(4096, 1, "auto", 1) == {} and mod.measured_counters(16384, 2, "auto", 1) == {}
+    assert mod.measured_counters(4096, 1, "auto", True) == {} and mod.measured_counters(16384, 2, "auto", True) == {}
 
 
 @gpu

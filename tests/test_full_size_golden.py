@@ -70,10 +70,8 @@ def test_oracle_is_pinned_at_4096(oracle, golden):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,variant", [("cfg3_add_4096_i20", "fused"), ("cfg3_add_4096_i20", "fused-fp64dem"),
-                                          ("cfg3_add_4096_i20", "fused-dem32"),
                                           ("cfg3_add_4096_i20", "pass"), ("cfg3_add_4096_i20", "fused-chunk48"),
-                                          ("cfg4_add_16384_i2", "fused"), ("cfg4_add_16384_i2", "fused-fp64dem"),
-                                          ("cfg4_add_16384_i2", "fused-dem32")])
+                                          ("cfg4_add_16384_i2", "fused"), ("cfg4_add_16384_i2", "fused-fp64dem")])
 def test_add_at_full_size_equals_the_reference(hip, golden, name, variant):
     z, idx = golden
     meta = idx[name]
@@ -87,10 +85,7 @@ def test_add_at_full_size_equals_the_reference(hip, golden, name, variant):
         if variant == "fused-fp64dem":
             c.set_option(wdpm_amd.OPT_DEM32, 0)
         elif variant.startswith("fused"):
-            assert c.get_option(wdpm_amd.OPT_DEM32) == 1       # the synthetic DEMs are decimal: the codes are in use ...
-            assert c.get_option(wdpm_amd.capi.OPT_DEM16) == 1  # ... and gentle enough for their 16-bit form
-            if variant == "fused-dem32":
-                c.set_option(wdpm_amd.capi.OPT_DEM16, 0)       # the 32-bit codes alone
+            assert c.get_option(wdpm_amd.OPT_DEM32) == 1       # the synthetic DEMs are decimal: the codes are in use
         md = c.run_block(meta["add_iters"], THRES)
         w = c.download_water()
     assert md == meta["max_diff"]

@@ -80,48 +80,6 @@ def test_random_rasters_match_oracle(hip, oracle, module, kernel, R, C, chunk):
     _compare_with_oracle(hip, oracle, module, R, C, seed=R * 1000 + C, iters=(1, 2, 25), kernel=kernel, chunk=chunk)
 
 
-@pytest.mark.parametrize("levels,R,C,chunk", [(2, 40, 230, 0), (2, 64, 1100, 30), (2, 301, 170, 48), (2, 5, 175, 3), (2, 1, 1, 0),
-                                              (2, 100, 2000, 24), (1, 100, 700, 0)])
-def test_dem_codes_as_16_bit_offsets(hip, oracle, levels, R, C, chunk):
-    """second level of the DEM codes (WDPM_OPT_DEM16): 16-bit offsets from one base per 48 columns of a row where no such
-    group spans more than 65 534 quanta - on by itself for gentle terrain, refused for steep terrain, same bits as the oracle
-    with it, with the 32-bit codes alone and with the fp64 DEM; NODATA cells, edge strips, ragged sizes, both edges of a group"""
-    rng = np.random.default_rng(R * 7 + C)
-    miss = -99999.0
-    y, x = np.mgrid[0:R, 0:C]
-    if levels == 2:      # 1 cm resolution, metres of relief per group: every group fits 16 bits
-        dem = np.round(300.0 + 3.0 * np.sin(x / 9.0) * np.cos(y / 5.0) + rng.normal(0, 0.5, (R, C)) - 0.02 * x, 2)
-    else:                # 0.1 mm resolution and 10 m steps inside the groups: only the 32-bit codes fit
-        dem = np.round(300.0 + 10.0 * ((x // 7) % 2) + rng.normal(0, 0.5, (R, C)), 4)
-    dem[rng.random((R, C)) < 0.05] = miss
-    if C > 100:
-        dem[:, 40:60] = miss                                        # a whole group without a valid cell, and its neighbours' edges
-    water = np.where(dem > miss, 0.3 * rng.random((R, C)), 0.0)
-    bd, bw = pad(dem, water, miss)
-    kw = dict(module="add", nrows=R, ncols=C, missingvalue=miss)
-    got = {}
-    with oracle.context(**kw) as o:
-        o.upload(bd, bw)
-        o.iterate(14)
-        want = o.download_water()
-    for mode in ("16", "32", "fp64"):
-        with hip.context(kernel=wdpm_amd.KERNEL_FUSED, chunk_rows=chunk, **kw) as g:
-            g.upload(bd, bw)
-            valid = bool((dem > miss).any())
-            assert g.get_option(wdpm_amd.OPT_DEM32) == int(valid)
-            assert g.get_option(wdpm_amd.capi.OPT_DEM16) == int(valid and levels == 2)
-            g.set_option(wdpm_amd.OPT_DEM32, 0 if mode == "fp64" else 2)     # 2: also on launches this small
-            if mode == "32":
-                g.set_option(wdpm_amd.capi.OPT_DEM16, 0)
-                assert g.get_option(wdpm_amd.capi.OPT_DEM16) == 0
-            else:
-                g.set_option(wdpm_amd.capi.OPT_DEM16, 1)              # honoured only for a DEM that passed the check
-                assert g.get_option(wdpm_amd.capi.OPT_DEM16) == int(valid and levels == 2 and mode == "16")
-            g.iterate(14)
-            got[mode] = g.download_water()
-        assert n_bit_diff(got[mode], want) == 0, mode
-
-
 @pytest.mark.parametrize("dem32", [0, 1])
 @pytest.mark.parametrize("module", ["add", "subtract"])
 @pytest.mark.parametrize("R,C,chunk", [(38, 398, 12), (100, 700, 0), (301, 170, 48), (64, 1100, 30), (5, 175, 3), (1, 1, 0)])

@@ -63,9 +63,6 @@ struct wdpm_ctx {
   int *d_dem32;                 /* the DEM as verified-lossless 32-bit codes (wdpm_kernels.h::DemCode) */
   DemCode code;                 /* code.q == d_dem32 while the uploaded DEM is encodable and the option is on */
   bool dem32_encodable;
-  unsigned short *d_dem16;      /* the codes as 16-bit offsets from d_gbase (DemCode::h, ::gb); code.h is set while they are in use */
-  int *d_gbase;
-  bool dem16_encodable;
   /* wdpm_iterate_overlapped: side stream for the interior launch and the event that joins it */
   hipStream_t side;
   hipEvent_t ev_fork, ev_join;

@@ -275,13 +275,9 @@ struct Prefetched {
   double NW[3][3], ND[3][3];
   wdpm_i3 qi[3];
   int qe[3][3];
-  int qh[3][3];      /* DEM32 == 2: 16-bit offsets (zero-extended by the load) ... */
-  int gbv[3];        /* ... and the lane's group base per row (interior waves) ... */
-  int ge[3][3];      /* ... or per column (edge waves clamp every column into the raster on its own) */
 };
 
-/* DEM32: 0 = the fp64 DEM, 1 = 32-bit codes, 2 = 16-bit offsets + group bases (wdpm_kernels.h::DemCode) */
-template <int MODULE, bool SZ_SAFE, int DEM32, bool FLUSH = false, bool MD = false>
+template <int MODULE, bool SZ_SAFE, bool DEM32, bool FLUSH = false, bool MD = false>
 __global__ void __launch_bounds__(256, WDPM_FUSED_MIN_WAVES)
 fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout,
                        const double *__restrict__ dem, const DemCode code, const SlabGeom g, const int nstrips,
@@ -418,9 +414,6 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
     int qoff[3];                     // the same for the 4-byte dem codes
 #pragma unroll
     for (int j = 0; j < 3; j++) qoff[j] = voff[j] / 2;
-    int hoff[3], goff[3];            // ... for the 2-byte offsets and the 4-byte group bases (one per kDemGroup columns)
-#pragma unroll
-    for (int j = 0; j < 3; j++) { hoff[j] = voff[j] / 4; goff[j] = 4 * ((voff[j] / 8) / kDemGroup); }
 
     // Prefetch of the three rows starting at r0 into raw registers.  The loads are issued with
     // inline asm (saddr form: wave-uniform row base in SGPRs + a per-lane byte offset) so that
@@ -436,18 +429,11 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
         const double *bw = win + (size_t)r * pitch;     // wave-uniform
         const double *bd = dem + (size_t)r * pitch;
         const int *bq = code.q + (size_t)r * pitch;
-        const unsigned short *bh = code.h + (size_t)r * pitch;
-        const int *bg = code.gb + (size_t)r * code.ngroups;
         if (!EDGE) {
           asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(P.NW[i][0]) : "v"(voff[0]), "s"(bw) : "memory");
           asm volatile("global_load_dwordx2 %0, %1, %2 offset:8" : "=v"(P.NW[i][1]) : "v"(voff[0]), "s"(bw) : "memory");
           asm volatile("global_load_dwordx2 %0, %1, %2 offset:16" : "=v"(P.NW[i][2]) : "v"(voff[0]), "s"(bw) : "memory");
-          if (DEM32 == 2) {
-            asm volatile("global_load_ushort %0, %1, %2" : "=v"(P.qh[i][0]) : "v"(hoff[0]), "s"(bh) : "memory");
-            asm volatile("global_load_ushort %0, %1, %2 offset:2" : "=v"(P.qh[i][1]) : "v"(hoff[0]), "s"(bh) : "memory");
-            asm volatile("global_load_ushort %0, %1, %2 offset:4" : "=v"(P.qh[i][2]) : "v"(hoff[0]), "s"(bh) : "memory");
-            asm volatile("global_load_dword %0, %1, %2" : "=v"(P.gbv[i]) : "v"(goff[0]), "s"(bg) : "memory");
-          } else if (DEM32) {
+          if (DEM32) {
             asm volatile("global_load_dwordx3 %0, %1, %2" : "=v"(P.qi[i]) : "v"(qoff[0]), "s"(bq) : "memory");
           } else {
             asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(P.ND[i][0]) : "v"(voff[0]), "s"(bd) : "memory");
@@ -458,10 +444,7 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
 #pragma unroll
           for (int j = 0; j < 3; j++) {
             asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(P.NW[i][j]) : "v"(voff[j]), "s"(bw) : "memory");
-            if (DEM32 == 2) {
-              asm volatile("global_load_ushort %0, %1, %2" : "=v"(P.qh[i][j]) : "v"(hoff[j]), "s"(bh) : "memory");
-              asm volatile("global_load_dword %0, %1, %2" : "=v"(P.ge[i][j]) : "v"(goff[j]), "s"(bg) : "memory");
-            } else if (DEM32) asm volatile("global_load_dword %0, %1, %2" : "=v"(P.qe[i][j]) : "v"(qoff[j]), "s"(bq) : "memory");
+            if (DEM32) asm volatile("global_load_dword %0, %1, %2" : "=v"(P.qe[i][j]) : "v"(qoff[j]), "s"(bq) : "memory");
             else asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(P.ND[i][j]) : "v"(voff[j]), "s"(bd) : "memory");
           }
         }
@@ -471,8 +454,6 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
     // no use can be scheduled above it.  YOUNGER = memory operations issued after the loads.
 #define WDPM_WAIT_W "+v"(P.NW[0][0]), "+v"(P.NW[0][1]), "+v"(P.NW[0][2]), "+v"(P.NW[1][0]), "+v"(P.NW[1][1]), \
                     "+v"(P.NW[1][2]), "+v"(P.NW[2][0]), "+v"(P.NW[2][1]), "+v"(P.NW[2][2])
-#define WDPM_WAIT_H "+v"(P.qh[0][0]), "+v"(P.qh[0][1]), "+v"(P.qh[0][2]), "+v"(P.qh[1][0]), "+v"(P.qh[1][1]), \
-                    "+v"(P.qh[1][2]), "+v"(P.qh[2][0]), "+v"(P.qh[2][1]), "+v"(P.qh[2][2])
 #define WDPM_WAIT_ROWS(YOUNGER)                                                                        \
   do {                                                                                                 \
     if (!DEM32)                                                                                        \
@@ -480,17 +461,6 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
                    : WDPM_WAIT_W, "+v"(P.ND[0][0]), "+v"(P.ND[0][1]), "+v"(P.ND[0][2]), "+v"(P.ND[1][0]), \
                      "+v"(P.ND[1][1]), "+v"(P.ND[1][2]), "+v"(P.ND[2][0]), "+v"(P.ND[2][1]),           \
                      "+v"(P.ND[2][2])                                                                  \
-                   :                                                                                   \
-                   : "memory");                                                                        \
-    else if (DEM32 == 2 && !EDGE)                                                                      \
-      asm volatile("s_waitcnt vmcnt(" #YOUNGER ")"                                                     \
-                   : WDPM_WAIT_W, WDPM_WAIT_H, "+v"(P.gbv[0]), "+v"(P.gbv[1]), "+v"(P.gbv[2])          \
-                   :                                                                                   \
-                   : "memory");                                                                        \
-    else if (DEM32 == 2)                                                                               \
-      asm volatile("s_waitcnt vmcnt(" #YOUNGER ")"                                                     \
-                   : WDPM_WAIT_W, WDPM_WAIT_H, "+v"(P.ge[0][0]), "+v"(P.ge[0][1]), "+v"(P.ge[0][2]), "+v"(P.ge[1][0]), \
-                     "+v"(P.ge[1][1]), "+v"(P.ge[1][2]), "+v"(P.ge[2][0]), "+v"(P.ge[2][1]), "+v"(P.ge[2][2]) \
                    :                                                                                   \
                    : "memory");                                                                        \
     else if (!EDGE)                                                                                    \
@@ -541,8 +511,7 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
         for (int j = 0; j < 3; j++) {
           // FLUSH: the block's threshold flush (WDPMCL.c:1059-1062) applied to the water as it arrives
           W[4 + i][j] = FLUSH && P.NW[i][j] < thres ? 0.0 : P.NW[i][j];
-          if (DEM32 == 2) D[4 + i][j] = dem16_decode(P.qh[i][j], EDGE ? P.ge[i][j] : P.gbv[i], code.k0, code.D, code.rD);
-          else if (DEM32) D[4 + i][j] = dem32_decode(EDGE ? P.qe[i][j] : P.qi[i][j], code.k0, code.D, code.rD);
+          if (DEM32) D[4 + i][j] = dem32_decode(EDGE ? P.qe[i][j] : P.qi[i][j], code.k0, code.D, code.rD);
           else D[4 + i][j] = P.ND[i][j];
         }
       if (MODULE == 2 && owed_here && A + 3 * n + 2 >= g.dr - 1 && A + 3 * n <= g.dr + 1) {   // wave-uniform, rare
@@ -642,7 +611,6 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
     write_staged(A + 3 * (nsteps - 1) - 4);    // the last step's rows
 #undef WDPM_WAIT_ROWS
 #undef WDPM_WAIT_W
-#undef WDPM_WAIT_H
   };
   if (edge) march(std::true_type{});
   else march(std::false_type{});
@@ -959,7 +927,7 @@ __global__ void dpp_probe_kernel(int *out) {
 /* Number of waves of the fused kernel the whole chip holds at once (CUs x blocks/CU x 4 waves),
  * from the occupancy API; cached per module.  All work items of a launch are made resident
  * together — one round, no tail — so the item count is sized to this. */
-template <int MODULE, bool SZ_SAFE, int DEM32 = 0>
+template <int MODULE, bool SZ_SAFE, bool DEM32 = false>
 static int resident_waves() {
   static std::atomic<int> cached{0};      // rank threads of one process launch concurrently: no plain statics
   if (cached.load(std::memory_order_relaxed)) return cached.load(std::memory_order_relaxed);
@@ -1094,12 +1062,10 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
   // ... and only pays on launches big enough for two waves per SIMD (see below): at one wave per SIMD
   // the wave's own latency chain is the limit and the nine decodes per step cost 3-5 % (size sweep in
   // profiles/r01: 512^2 - 3072^2 slower with codes, 4096^2 and up 5-12 % faster).
-  const bool big = (long long)(out_last - A0 + 1) * nstrips >= 36LL * resident_waves<0, false, 1>();
+  const bool big = (long long)(out_last - A0 + 1) * nstrips >= 36LL * resident_waves<0, false, true>();
   const bool dem32 = fast && module != 2 && code.q != nullptr && (big || code.force);
-  const bool dem16 = dem32 && code.h != nullptr;          // the codes once more as 16-bit offsets: 2.08 B per cell instead of 4
   int slots = module == 2 ? (fast ? resident_waves<2, false>() : resident_waves<2, true>())
-              : dem16     ? resident_waves<0, false, 2>()
-              : dem32     ? resident_waves<0, false, 1>()
+              : dem32     ? resident_waves<0, false, true>()
               : fast      ? resident_waves<0, false>()
                           : resident_waves<0, true>();
   {
@@ -1159,12 +1125,11 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
 #define WDPM_LAUNCH(...) hipLaunchKernelGGL((fused_iteration_kernel<__VA_ARGS__>), grid, block, 0, s, w_in, w_out, dem, code, g, nstrips, nitems, H, A0, out_last, totaldrain, thres, module == 2 ? drain_owed : 0, tf, mda)
 #define WDPM_LAUNCH_FM(M, Z, D32) do { if (fold_md) { if (flush) WDPM_LAUNCH(M, Z, D32, true, true); else WDPM_LAUNCH(M, Z, D32, false, true); } \
                                        else { if (flush) WDPM_LAUNCH(M, Z, D32, true, false); else WDPM_LAUNCH(M, Z, D32, false, false); } } while (0)
-  if (module == 2 && fast) { if (flush) WDPM_LAUNCH(2, false, 0, true, false); else WDPM_LAUNCH(2, false, 0, false, false); }
-  else if (module == 2) WDPM_LAUNCH(2, true, 0, false, false);
-  else if (dem16) WDPM_LAUNCH_FM(0, false, 2);
-  else if (dem32) WDPM_LAUNCH_FM(0, false, 1);
-  else if (fast) WDPM_LAUNCH_FM(0, false, 0);
-  else WDPM_LAUNCH(0, true, 0, false, false);
+  if (module == 2 && fast) { if (flush) WDPM_LAUNCH(2, false, false, true, false); else WDPM_LAUNCH(2, false, false, false, false); }
+  else if (module == 2) WDPM_LAUNCH(2, true, false, false, false);
+  else if (dem32) WDPM_LAUNCH_FM(0, false, true);
+  else if (fast) WDPM_LAUNCH_FM(0, false, false);
+  else WDPM_LAUNCH(0, true, false, false, false);
 #undef WDPM_LAUNCH_FM
 #undef WDPM_LAUNCH
   return hipGetLastError();
