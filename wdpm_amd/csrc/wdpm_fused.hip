@@ -9,8 +9,11 @@
  *  - A wave64 is the unit of work; waves never synchronise with each other (no barriers; LDS is
  *    only a wave-private transpose buffer for the stores).  Lane m owns raster columns
  *    c0+3m .. c0+3m+2, so a wave covers a 192-column strip and a 64-lane row load is one
- *    contiguous 1536-byte segment.  Waves per SIMD: one for add/subtract on the fp64 DEM (HBM-bound
- *    already), two for drain (latency-bound) and for add/subtract on the DEM codes below.
+ *    contiguous 1536-byte segment.  Waves per SIMD: one for add/subtract on the fp64 DEM, two for drain
+ *    (bound by instruction issue) and for add/subtract on the DEM codes below.  Neither resource is idle in
+ *    the add kernel: fp64 VALU issue is ~85 % busy (SQ_INSTS_VALU x 4 / SIMD over GRBM_GUI_ACTIVE / 8) while
+ *    the memory system carries 4.4-4.7 TB/s, what a plain 2-read : 1-write triad reaches on this chip
+ *    ("what the add kernel is bound by").
  *  - The wave marches down a chunk of rows with a 7-row window held in registers (dem + water,
  *    3 columns per lane).  Each step loads 3 new rows and applies, in this order, row alignment
  *    oi=1 to rows 3n..3n+2, oi=2 to rows 3n-2..3n, oi=3 to rows 3n-4..3n-2 — a skew that respects
