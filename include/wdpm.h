@@ -320,6 +320,15 @@ int  wdpm_group_enqueue_stats(wdpm_group *grp, double *seconds, double *exchange
  *   setting 1 is honoured only for a DEM that passed the check; the kernel then uses the codes on
  *   launches large enough for them to pay (>= 4096^2 or so), setting 2 on launches of any size.  WDPM_DEM32=0 in the environment
  *   disables the encoding altogether, WDPM_DEM32=2 makes 2 the default.  The CPU restatement reports 0.
+ * WDPM_OPT_WATER_KINDS (get/set; round 3): what the library's scan of every uploaded water raster found, as a bit mask -
+ *   1: a -0.0 depth (= WDPM_OPT_SIGNED_ZERO_SAFE), 2: a negative depth (forgotten again once a threshold flush with
+ *   thres >= 0 has been applied), 4: NaN, a depth above 1e290 or water on a NODATA cell.  With none of them every cell that
+ *   may not give water (dry, NODATA) holds +0.0 exactly, a state no operation of the loop can leave, and the iteration kernels
+ *   then run variants that spend no instructions on the reference's centre test (WDPMCL.c:1099: `bigwater > 0 &&
+ *   bigdem > missingvalue`) - such a centre's transfers come out as zero by themselves; WDPM_OPT_PLAIN_WATER (get) says
+ *   whether they run now.  Setting ORs bits in: a multi-GPU driver whose transport writes halo rows straight into device
+ *   memory must OR the mask over all ranks after every upload and set it on each (wdpm_rowblock.c does).  WDPM_PLAIN=0 in the
+ *   environment keeps the gated variants.  Results are identical either way.
  * WDPM_OPT_TILES (get/set): 1 (default; WDPM_TILES=0 in the environment: 0) = dry-tile skipping.  The reference
  *   skips dry centres cell by cell (WDPMCL.c:1099); the iteration kernel keeps, per water raster, one flag per
  *   tile (the output block of one wave) saying "all +0.0", and a wave whose tile and eight neighbours are flagged
@@ -331,7 +340,8 @@ int  wdpm_group_enqueue_stats(wdpm_group *grp, double *seconds, double *exchange
  *   carry n KiB guard bands; this counts guard bytes that were overwritten (0 = no kernel wrote outside its buffer; always 0
  *   without the variable).  A debugging aid: the GPU pool has no address sanitizer. */
 enum { WDPM_OPT_SIGNED_ZERO_SAFE = 1, WDPM_OPT_DEM32 = 2, WDPM_OPT_TILES = 3, WDPM_OPT_TILES_SEEN = 4,
-       WDPM_OPT_TILES_WORKED = 5, WDPM_OPT_SPARSE = 6, WDPM_OPT_GUARD_BAD = 7 };
+       WDPM_OPT_TILES_WORKED = 5, WDPM_OPT_SPARSE = 6, WDPM_OPT_GUARD_BAD = 7, WDPM_OPT_WATER_KINDS = 8,
+       WDPM_OPT_PLAIN_WATER = 9 };
 int wdpm_get_option(wdpm_ctx *ctx, int32_t key, int64_t *value);
 int wdpm_set_option(wdpm_ctx *ctx, int32_t key, int64_t value);
 

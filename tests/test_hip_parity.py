@@ -739,3 +739,60 @@ def test_guard_bands_notice_a_stray_write(hip):
     finally:
         hip.dll.wdpm_destroy(c._h)          # not through close(): that one would (rightly) complain
         c._h = None
+
+
+@pytest.mark.parametrize("module", ["add", "drain"])
+def test_water_kinds_and_the_gate_free_variants(hip, oracle, module):
+    """WDPM_OPT_WATER_KINDS / WDPM_OPT_PLAIN_WATER (round 3): the kernels without the centre gate run exactly while the library
+    knows that every cell which may not give water holds +0.0 - what its scan of every upload finds, what a threshold flush
+    removes, what a partial upload or a raw pointer brings back - and the bits are the oracle's in every one of these states
+    (WDPMCL.c:1099 is the test they leave out)"""
+    from wdpm_amd.capi import OPT_PLAIN_WATER, OPT_WATER_KINDS
+    R, C = 130, 420
+    dem, water, miss = random_case(4242, R, C)
+    nodata = dem <= miss
+    assert nodata.any() and (water[nodata] == 0).all() and (water >= 0).all()
+    cases = {
+        "clean": (water, 0),
+        "minus_99999_on_nodata": (np.where(nodata, -99999.0, water), 2),       # what the reference's own output rasters hold there
+        "negative_on_a_valid_cell": (np.where((np.arange(R * C).reshape(R, C) % 97) == 0, -0.25, water), 2),
+        "water_on_nodata": (np.where(nodata, 0.125, water), 4),
+        "nan": (np.where((np.arange(R * C).reshape(R, C) % 1013) == 5, np.nan, water), 4),
+        "negative_zero": (np.where(water == 0, -0.0, water), 1),
+    }
+    for name, (w, kinds) in cases.items():
+        bd, bw = pad(dem, w, miss)
+        kw = dict(module=module, nrows=R, ncols=C, missingvalue=miss)
+        if module == "drain":
+            dr, dc = find_drain(bd)
+            kw.update(drainrow=dr, draincol=dc)
+        with hip.context(kernel=wdpm_amd.KERNEL_FUSED, **kw) as g, oracle.context(**kw) as o:
+            for c in (g, o):
+                c.upload(bd, bw)
+                c.totaldrain = 0.0
+            assert g.get_option(OPT_WATER_KINDS) == kinds, name
+            assert g.get_option(OPT_PLAIN_WATER) == int(kinds == 0), name
+            for block in range(3):
+                assert g.run_block(7, 1e-5) == o.run_block(7, 1e-5), (name, block)     # NaN == NaN is False: max diff never is NaN
+                assert n_bit_diff(g.download_water(), o.download_water()) == 0, (name, block)
+                assert g.totaldrain == o.totaldrain
+                # the flush of the first launch removes what is negative; the rest stays for good
+                assert g.get_option(OPT_WATER_KINDS) == (kinds & ~2), (name, block)
+            # a partial upload brings negative depths back (until the next flush) ...
+            rows = bw[10:13].copy()
+            rows[1, 5:9] = -1.0
+            g.upload_rows(10, rows)
+            o.upload_rows(10, rows)
+            assert g.get_option(OPT_WATER_KINDS) == (kinds & ~2) | 2 and g.get_option(OPT_PLAIN_WATER) == 0
+            g.iterate(3)                                                        # no flush: still there (gated variants)
+            o.iterate(3)
+            assert g.get_option(OPT_WATER_KINDS) & 2
+            assert g.run_block(5, 1e-5) == o.run_block(5, 1e-5)
+            assert n_bit_diff(g.download_water(), o.download_water()) == 0, name
+            assert g.get_option(OPT_WATER_KINDS) == (kinds & ~2)
+            # ... and whoever takes the raw device pointer may write anything
+            g.water_ptr()
+            assert g.get_option(OPT_WATER_KINDS) & 4 and g.get_option(OPT_PLAIN_WATER) == 0
+            g.iterate(4)
+            o.iterate(4)
+            assert n_bit_diff(g.download_water(), o.download_water()) == 0, name

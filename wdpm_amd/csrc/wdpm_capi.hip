@@ -55,6 +55,7 @@ static int ensure_drained(wdpm_ctx *x);
 int wdpm_apply_owed_drain(wdpm_ctx *x) { return ensure_drained(x); }
 static int ensure_flushed(wdpm_ctx *x);
 int wdpm_apply_owed_flush(wdpm_ctx *x) { return ensure_flushed(x); }
+static void flushed_whole(wdpm_ctx *x, double thres);
 
 int wdpm_stream_sync(wdpm_ctx *x, hipStream_t s) {
   if (!x->comm) {
@@ -144,6 +145,7 @@ static int ensure_flushed(wdpm_ctx *x) {
   if (!x->flush_pending) return 0;
   HIP_TRY(wdpm_launch_flush_snapshot(x->d_w[x->cur], x->d_w[x->cur], x->cells, x->flush_thres, x->stream));
   x->flush_pending = false;
+  flushed_whole(x, x->flush_thres);
   return 0;
 }
 
@@ -156,6 +158,7 @@ static int ensure_private(wdpm_ctx *x) {
   if (x->flush_pending) {
     HIP_TRY(wdpm_launch_flush_snapshot(x->d_w[x->cur], x->d_w[t], x->cells, x->flush_thres, x->stream));
     x->flush_pending = false;
+    flushed_whole(x, x->flush_thres);      /* (the copy that becomes current is the flushed one) */
   } else {
     HIP_TRY(hipMemcpyAsync(x->d_w[t], x->d_w[x->cur], x->cells * sizeof(double), hipMemcpyDeviceToDevice, x->stream));
   }
@@ -256,6 +259,8 @@ int wdpm_create(wdpm_ctx **out, const wdpm_params *p) {
   }
   x->cur = 0;
   x->signed_zero_safe = false;
+  x->w_negative = false;
+  x->w_odd = true;                /* nothing known about the rasters before the first upload */
   x->launches = 0;
   x->ms = 0.0;
   x->steady_launches = 0;
@@ -361,16 +366,30 @@ int wdpm_synchronize(wdpm_ctx *x) {
 }
 
 /* ---- data movement ---------------------------------------------------------------------- */
-/* after water has been written to rows [row, row+nrows): does it hold a -0.0? */
+/* after water has been written to rows [row, row+nrows): what kinds of depth does it hold (wdpm_launch_scan_water)? */
 static int note_negzero(wdpm_ctx *x, int row, int nrows) {
+  const size_t off = (size_t)row * x->g.ncp;
   HIP_TRY(hipMemsetAsync(x->d_bits, 0, sizeof(unsigned long long), x->stream));
-  HIP_TRY(wdpm_launch_scan_negzero(x->d_w[x->cur] + (size_t)row * x->g.ncp, (size_t)nrows * x->g.ncp, x->d_bits, x->stream));
+  HIP_TRY(wdpm_launch_scan_water(x->d_w[x->cur] + off, x->d_dem + off, (size_t)nrows * x->g.ncp, x->d_bits, x->stream));
   HIP_TRY(hipMemcpyAsync(x->h_pin, x->d_bits, sizeof(double), hipMemcpyDeviceToHost, x->stream));
   if (wdpm_stream_sync(x, x->stream)) return 1;
   unsigned long long bits;
   memcpy(&bits, x->h_pin, sizeof bits);
-  if (bits) x->signed_zero_safe = true;
+  if (bits & WDPM_WATER_NEGZERO) x->signed_zero_safe = true;
+  if (bits & WDPM_WATER_NEGATIVE) x->w_negative = true;
+  if (bits & WDPM_WATER_ODD) x->w_odd = true;
   return 0;
+}
+
+/* the block's threshold flush has just been applied to the whole current raster: with thres >= 0 no negative depth is left */
+static void flushed_whole(wdpm_ctx *x, double thres) {
+  if (thres >= 0.0) x->w_negative = false;
+}
+
+static bool plain_water(const wdpm_ctx *x) {
+  static std::atomic<int> env{-1};
+  if (env < 0) { const char *e = getenv("WDPM_PLAIN"); env = e ? atoi(e) : 1; }      /* WDPM_PLAIN=0: gated variants only (A/B, tests) */
+  return env != 0 && !x->signed_zero_safe && !x->w_negative && !x->w_odd;
 }
 
 /* Try to express the DEM just uploaded as 32-bit codes k with dem == (k + k0) / 10^e bit for bit
@@ -414,7 +433,7 @@ int wdpm_upload(wdpm_ctx *x, const double *bigdem, const double *bigwater) {
   HIP_TRY(hipMemcpyAsync(x->d_dem, bigdem, bytes, hipMemcpyHostToDevice, x->stream));
   HIP_TRY(hipMemcpyAsync(x->d_w[x->cur], bigwater, bytes, hipMemcpyHostToDevice, x->stream));
   HIP_TRY(wdpm_launch_mark_nodata(x->d_dem, x->cells, x->g.miss, x->stream));
-  x->signed_zero_safe = false;
+  x->signed_zero_safe = x->w_negative = x->w_odd = false;
   if (note_negzero(x, 0, x->g.rows)) return 1;
   if (encode_dem(x)) return 1;
   return 0;
@@ -444,7 +463,7 @@ int wdpm_upload_unpadded(wdpm_ctx *x, const double *dem, const double *water, co
   x->old = a;
   x->flush_thres = -__builtin_inf();
   HIP_TRY(hipMemsetAsync(x->d_w[a], 0, x->cells * sizeof(double), x->stream));
-  x->signed_zero_safe = false;
+  x->signed_zero_safe = x->w_negative = x->w_odd = false;
   if (note_negzero(x, 0, x->g.rows)) return 1;
   return encode_dem(x);
 }
@@ -523,7 +542,7 @@ int wdpm_upload_water(wdpm_ctx *x, const double *bigwater) {
   if (bind(x)) return 1;
   if (ensure_fresh_slot(x)) return 1;
   HIP_TRY(hipMemcpyAsync(x->d_w[x->cur], bigwater, x->cells * sizeof(double), hipMemcpyHostToDevice, x->stream));
-  x->signed_zero_safe = false;
+  x->signed_zero_safe = x->w_negative = x->w_odd = false;
   return note_negzero(x, 0, x->g.rows);
 }
 
@@ -617,6 +636,8 @@ int wdpm_copy_rows(wdpm_ctx *dst, int32_t dst_row, wdpm_ctx *src, int32_t src_ro
 int wdpm_get_option(wdpm_ctx *x, int32_t key, int64_t *value) {
   if (!value) return fail("wdpm_get_option: null argument");
   if (key == WDPM_OPT_SIGNED_ZERO_SAFE) *value = x->signed_zero_safe ? 1 : 0;
+  else if (key == WDPM_OPT_WATER_KINDS) *value = (x->signed_zero_safe ? WDPM_WATER_NEGZERO : 0) | (x->w_negative ? WDPM_WATER_NEGATIVE : 0) | (x->w_odd ? WDPM_WATER_ODD : 0);
+  else if (key == WDPM_OPT_PLAIN_WATER) *value = plain_water(x) ? 1 : 0;
   else if (key == WDPM_OPT_DEM32) *value = x->code.q ? 1 : 0;
   else if (key == WDPM_OPT_TILES) *value = x->tiles_mode;
   else if (key == WDPM_OPT_TILES_SEEN) *value = x->stat_tiles;
@@ -630,6 +651,10 @@ int wdpm_get_option(wdpm_ctx *x, int32_t key, int64_t *value) {
 int wdpm_set_option(wdpm_ctx *x, int32_t key, int64_t value) {
   if (key == WDPM_OPT_SIGNED_ZERO_SAFE) {
     x->signed_zero_safe = value != 0;
+  } else if (key == WDPM_OPT_WATER_KINDS) {        /* OR-ed in: what a multi-GPU driver found on the other ranks */
+    if (value & WDPM_WATER_NEGZERO) x->signed_zero_safe = true;
+    if (value & WDPM_WATER_NEGATIVE) x->w_negative = true;
+    if (value & WDPM_WATER_ODD) x->w_odd = true;
   } else if (key == WDPM_OPT_DEM32) {
     /* switching it on is honoured only for a DEM that passed the device's bit-for-bit check */
     x->code.q = (value != 0 && x->dem32_encodable) ? x->d_dem32 : nullptr;
@@ -664,6 +689,7 @@ int wdpm_get_totaldrain(wdpm_ctx *x, double *v) {
 int wdpm_water_ptr(wdpm_ctx *x, void **ptr) {
   if (bind(x) || ensure_private(x)) return 1;   /* the caller may write through it */
   x->zero_valid[x->cur] = false;
+  x->w_odd = true;                               /* ... anything at all: the gated kernel variants from here on */
   *ptr = x->d_w[x->cur];
   return 0;
 }
@@ -683,6 +709,7 @@ int wdpm_begin_block(wdpm_ctx *x, double thres) {
     HIP_TRY(wdpm_launch_flush_snapshot(x->d_w[x->cur], x->d_w[t], x->cells, thres, x->stream));
     x->zero_valid[t] = false;
     x->old = t;
+    flushed_whole(x, thres);
   }
   x->flush_thres = thres;
   HIP_TRY(hipMemcpyAsync(x->d_scal + 1, x->d_scal, sizeof(double), hipMemcpyDeviceToDevice, x->stream)); /* olddrain */
@@ -769,7 +796,9 @@ int wdpm_iterate(wdpm_ctx *x, int32_t n_iter) {
       }
       HIP_TRY(wdpm_launch_fused(x->p.module, x->d_w[x->cur], x->d_w[t], x->d_dem, x->code, x->g, chunk_rows,
                                 x->signed_zero_safe ? 1 : 0, x->flush_pending ? &x->flush_thres : nullptr,
-                                x->drain_owed ? 1 : 0, x->d_scal, x->stream, track ? &tp : nullptr, md.old ? &md : nullptr));
+                                x->drain_owed ? 1 : 0, x->d_scal, x->stream, track ? &tp : nullptr, md.old ? &md : nullptr,
+                                plain_water(x) ? 1 : 0));
+      if (x->flush_pending) flushed_whole(x, x->flush_thres);   /* the launch flushed every value it loaded, and it loaded them all */
       if (md.old) x->md_valid = true;
       if (track && tp.maintained) {
         if (tp.nstrips != x->tile_nstrips || tp.H != x->tile_H || tp.nchunks != x->tile_nchunks) {
@@ -833,6 +862,7 @@ int wdpm_iterate_overlapped(wdpm_ctx *x, int32_t n_iter, int32_t top_rows, int32
   double *w_out = x->d_w[t_slot];
   const int szs = x->signed_zero_safe ? 1 : 0;
   const double *flush = x->flush_pending ? &x->flush_thres : nullptr;
+  const int plain = plain_water(x) ? 1 : 0;
   const bool fold = x->md_hint && !x->signed_zero_safe;     /* (usable: fused kernel, not the drain module) */
   x->md_hint = x->md_valid = false;
   MaxDiffArgs md{fold ? x->d_w[x->old] : nullptr, x->flush_thres, x->md_lo, x->md_hi, x->d_md};
@@ -850,14 +880,14 @@ int wdpm_iterate_overlapped(wdpm_ctx *x, int32_t n_iter, int32_t top_rows, int32
   HIP_TRY(hipEventRecord(x->ev_fork, x->stream));               /* w_in is complete here */
   if (t_last >= 0)
     HIP_TRY(wdpm_launch_fused_rows(x->p.module, w_in, w_out, x->d_dem, x->code, x->g, 0, t_last, x->p.chunk_rows, szs, flush,
-                                   0, x->d_scal, x->stream, nullptr, mdp));
+                                   0, x->d_scal, x->stream, nullptr, mdp, 0, plain));
   if (b_first < rows)
     HIP_TRY(wdpm_launch_fused_rows(x->p.module, w_in, w_out, x->d_dem, x->code, x->g, b_first - 2, rows - 1, x->p.chunk_rows,
-                                   szs, flush, 0, x->d_scal, x->stream, nullptr, mdp));
+                                   szs, flush, 0, x->d_scal, x->stream, nullptr, mdp, 0, plain));
   HIP_TRY(hipStreamWaitEvent(x->side, x->ev_fork, 0));
   HIP_TRY(wdpm_launch_fused_rows(x->p.module, w_in, w_out, x->d_dem, x->code, x->g, t_last >= 0 ? t_last - 1 : 0,
                                  b_first < rows ? b_first - 1 : rows - 1, x->p.chunk_rows, szs, flush, 0, x->d_scal, x->side, nullptr, mdp,
-                                 x->comm ? 8 : 0));   /* 8 of 256 CUs stay free for the RCCL kernels of the refresh that follows */
+                                 x->comm ? 8 : 0, plain));   /* 8 of 256 CUs stay free for the RCCL kernels of the refresh that follows */
   if (x->timing) {
     HIP_TRY(hipEventRecord(ep.b, x->side));
     x->pending.push_back(ep);
@@ -867,6 +897,7 @@ int wdpm_iterate_overlapped(wdpm_ctx *x, int32_t n_iter, int32_t top_rows, int32
   x->zero_valid[t_slot] = false;   /* three windows, not the tiling the flags are kept for */
   if (fold) x->md_valid = true;
   x->cur = t_slot;
+  if (x->flush_pending) flushed_whole(x, x->flush_thres);
   x->flush_pending = false;
   x->launches += 3;
   return 0;

@@ -58,6 +58,9 @@ struct wdpm_ctx {
   unsigned *d_sum_flag;
   int kernel;                   /* resolved WDPM_KERNEL_* */
   bool signed_zero_safe;        /* a -0.0 depth was uploaded (or the caller asked): exact-zero stencil variant */
+  bool w_negative, w_odd;       /* the current raster may hold negative depths (until the next threshold flush with thres >= 0) /
+                                   NaN, absurd depths or water on NODATA cells (for good): wdpm_kernels.h::wdpm_launch_scan_water.
+                                   With neither, and no -0.0, the gate-free kernel variants run (wdpm_fused.hip: PLAIN) */
   struct GuardedBuffer { char *base; size_t bytes; };   /* base = start of the front guard band; bytes = payload between the bands */
   std::vector<GuardedBuffer> guards;   /* WDPM_GUARD_KB: the buffers wdpm_get_option(WDPM_OPT_GUARD_BAD) inspects */
   int *d_dem32;                 /* the DEM as verified-lossless 32-bit codes (wdpm_kernels.h::DemCode) */

@@ -105,7 +105,14 @@ __device__ __forceinline__ void step_drain(const double dc, double &wc, const do
 /* one 3x3 block of one colour pass: centre (1,1), neighbours in row-major order.  OUTLET (drain
  * only): this block may touch the outlet cell, run runoffd()'s outlet branch too; the caller knows
  * wave-uniformly that it cannot for all but a handful of the raster's blocks. */
-template <int MODULE, bool SZ_SAFE, bool OUTLET = true>
+/* PLAIN (only with !SZ_SAFE): the caller knows that every cell which may not give water - dry, NODATA, outside the slab - holds
+ * +0.0 exactly (wdpm_kernels.h::wdpm_launch_scan_water; no operation of the loop leaves that state).  The centre test of the
+ * sweep (WDPMCL.c:1099) then costs nothing: for a centre depth of +0.0 the neighbour steps below come out as f = +-0 by
+ * themselves, whatever the elevations - finite centre: dem_c > en gives x = w_c = 0, otherwise ht = dem_c - en <= 0 and
+ * max(ht / 8, -0.0) = +-0; NODATA centre (dem = +inf): inf > en gives x = w_c = 0, and next to a NODATA neighbour ht is NaN,
+ * which v_max turns into -0.0 - and w + (+-0) == w, w - |+-0| == w for every w that is not -0.0.  (drain: the same through
+ * min(max(x / 8, -0.0), w_c = 0).)  Four instructions per block less for add, eight for drain. */
+template <int MODULE, bool SZ_SAFE, bool OUTLET = true, bool PLAIN = false>
 __device__ __forceinline__ void block_update(
     double &w00, double &w01, double &w02, double &w10, double &w11, double &w12, double &w20, double &w21,
     double &w22, const double d00, const double d01, const double d02, const double d10, const double d11,
@@ -114,7 +121,16 @@ __device__ __forceinline__ void block_update(
     DrainState &ds) {
   double wc = w11;
   bool gate = (wc > 0.0) & (d11 < WDPM_INF);            // WDPMCL.c:1099
-  if (MODULE == 2 && !OUTLET && !SZ_SAFE) {
+  if (MODULE == 2 && !OUTLET && !SZ_SAFE && PLAIN) {
+    flow_drain_nz(d11, wc, d00, w00);
+    flow_drain_nz(d11, wc, d01, w01);
+    flow_drain_nz(d11, wc, d02, w02);
+    flow_drain_nz(d11, wc, d10, w10);
+    flow_drain_nz(d11, wc, d12, w12);
+    flow_drain_nz(d11, wc, d20, w20);
+    flow_drain_nz(d11, wc, d21, w21);
+    flow_drain_nz(d11, wc, d22, w22);
+  } else if (MODULE == 2 && !OUTLET && !SZ_SAFE) {
     const double dce = gate ? d11 : -WDPM_INF;           // see flow_drain_nz
     wc = gate ? wc : 0.0;                                // its clamp needs a centre depth >= +0
     flow_drain_nz(dce, wc, d00, w00);
@@ -186,8 +202,8 @@ __device__ __forceinline__ void block_update(
     const unsigned long long m = __ballot(ds.hit);
     if (m) ds.td = wave_read(ds.td, __ffsll((long long)m) - 1);
   } else if (!SZ_SAFE) {
-    // no -0.0 in the raster: the gate rides on the centre elevation (see flow_add_nz)
-    const double dce = gate ? d11 : -WDPM_INF;
+    // no -0.0 in the raster: the gate rides on the centre elevation (see flow_add_nz) - or is not needed at all (PLAIN)
+    const double dce = PLAIN ? d11 : (gate ? d11 : -WDPM_INF);
     flow_add_nz(dce, wc, d00, w00);
     flow_add_nz(dce, wc, d01, w01);
     flow_add_nz(dce, wc, d02, w02);
@@ -210,7 +226,7 @@ __device__ __forceinline__ void block_update(
 }
 
 /* the three column alignments oj = 1,2,3 of one row alignment, on window slots S0..S0+2 */
-template <int MODULE, bool SZ_SAFE, int S0, bool OUTLET>
+template <int MODULE, bool SZ_SAFE, int S0, bool OUTLET, bool PLAIN = false>
 __device__ __forceinline__ void stage_impl(double (&W)[7][3], const double (&D)[7][3], const int row_s0,
                                            const int drain_row, const bool (&cdr)[5], DrainState &ds) {
   const bool rd0 = MODULE == 2 && OUTLET && row_s0 == drain_row;
@@ -218,21 +234,21 @@ __device__ __forceinline__ void stage_impl(double (&W)[7][3], const double (&D)[
   const bool rd2 = MODULE == 2 && OUTLET && row_s0 + 2 == drain_row;
   constexpr int a = S0, b = S0 + 1, c = S0 + 2;
   // oj = 1: own columns 0,1,2
-  block_update<MODULE, SZ_SAFE, OUTLET>(W[a][0], W[a][1], W[a][2], W[b][0], W[b][1], W[b][2], W[c][0], W[c][1], W[c][2],
+  block_update<MODULE, SZ_SAFE, OUTLET, PLAIN>(W[a][0], W[a][1], W[a][2], W[b][0], W[b][1], W[b][2], W[c][0], W[c][1], W[c][2],
                        D[a][0], D[a][1], D[a][2], D[b][0], D[b][1], D[b][2], D[c][0], D[c][1], D[c][2],
                        rd0, rd1, rd2, cdr[0], cdr[1], cdr[2], ds);
   // oj = 2: own columns 1,2 + column 0 of the next lane
   double wa0 = lane_next(W[a][0]), wb0 = lane_next(W[b][0]), wc0 = lane_next(W[c][0]);
   const double da0 = lane_next(D[a][0]), db0 = lane_next(D[b][0]),
                dc0 = lane_next(D[c][0]);
-  block_update<MODULE, SZ_SAFE, OUTLET>(W[a][1], W[a][2], wa0, W[b][1], W[b][2], wb0, W[c][1], W[c][2], wc0,
+  block_update<MODULE, SZ_SAFE, OUTLET, PLAIN>(W[a][1], W[a][2], wa0, W[b][1], W[b][2], wb0, W[c][1], W[c][2], wc0,
                        D[a][1], D[a][2], da0, D[b][1], D[b][2], db0, D[c][1], D[c][2], dc0,
                        rd0, rd1, rd2, cdr[1], cdr[2], cdr[3], ds);
   // oj = 3: own column 2 + columns 0,1 of the next lane
   double wa1 = lane_next(W[a][1]), wb1 = lane_next(W[b][1]), wc1 = lane_next(W[c][1]);
   const double da1 = lane_next(D[a][1]), db1 = lane_next(D[b][1]),
                dc1 = lane_next(D[c][1]);
-  block_update<MODULE, SZ_SAFE, OUTLET>(W[a][2], wa0, wa1, W[b][2], wb0, wb1, W[c][2], wc0, wc1,
+  block_update<MODULE, SZ_SAFE, OUTLET, PLAIN>(W[a][2], wa0, wa1, W[b][2], wb0, wb1, W[c][2], wc0, wc1,
                        D[a][2], da0, da1, D[b][2], db0, db1, D[c][2], dc0, dc1,
                        rd0, rd1, rd2, cdr[2], cdr[3], cdr[4], ds);
   // hand the borrowed columns back to lane+1; lane 0 keeps its own (nothing to its left)
@@ -252,7 +268,7 @@ __device__ __forceinline__ void stage_impl(double (&W)[7][3], const double (&D)[
  * those rows are never stored (a chunk stores from row A+2; for A = 0 the centre row is the raster's border or a slab's
  * first halo row, which is wrong from the first iteration after a refresh on anyway): dead work.  Leaving those three stage
  * executions out saves 3 of 3 (H/3 + 2): 9 % of a 27-row chunk, 5.6 % at 48 rows, 0.4 % at 780. */
-template <int MODULE, bool SZ_SAFE, int NSTAGES = 3>
+template <int MODULE, bool SZ_SAFE, int NSTAGES = 3, bool PLAIN = false>
 __device__ __forceinline__ void three_stages(double (&W)[7][3], const double (&D)[7][3], const int rbase,
                                              const int drain_row, const bool (&cdr)[5], DrainState &ds) {
   if (MODULE == 2 && drain_row >= rbase && drain_row <= rbase + 6) {           // wave-uniform, rare
@@ -260,9 +276,9 @@ __device__ __forceinline__ void three_stages(double (&W)[7][3], const double (&D
     if (NSTAGES >= 2) stage_impl<MODULE, SZ_SAFE, 2, true>(W, D, rbase + 2, drain_row, cdr, ds);   // oi = 2 on rows 3n-2 .. 3n
     if (NSTAGES >= 3) stage_impl<MODULE, SZ_SAFE, 0, true>(W, D, rbase + 0, drain_row, cdr, ds);   // oi = 3 on rows 3n-4 .. 3n-2
   } else {
-    stage_impl<MODULE, SZ_SAFE, 4, false>(W, D, rbase + 4, drain_row, cdr, ds);
-    if (NSTAGES >= 2) stage_impl<MODULE, SZ_SAFE, 2, false>(W, D, rbase + 2, drain_row, cdr, ds);
-    if (NSTAGES >= 3) stage_impl<MODULE, SZ_SAFE, 0, false>(W, D, rbase + 0, drain_row, cdr, ds);
+    stage_impl<MODULE, SZ_SAFE, 4, false, PLAIN>(W, D, rbase + 4, drain_row, cdr, ds);
+    if (NSTAGES >= 2) stage_impl<MODULE, SZ_SAFE, 2, false, PLAIN>(W, D, rbase + 2, drain_row, cdr, ds);
+    if (NSTAGES >= 3) stage_impl<MODULE, SZ_SAFE, 0, false, PLAIN>(W, D, rbase + 0, drain_row, cdr, ds);
   }
 }
 
@@ -280,7 +296,7 @@ struct Prefetched {
   int qe[3][3];
 };
 
-template <int MODULE, bool SZ_SAFE, bool DEM32, bool FLUSH = false, bool MD = false>
+template <int MODULE, bool SZ_SAFE, bool DEM32, bool FLUSH = false, bool MD = false, bool PLAIN = false>
 __global__ void __launch_bounds__(256, WDPM_FUSED_MIN_WAVES)
 fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout,
                        const double *__restrict__ dem, const DemCode code, const SlabGeom g, const int nstrips,
@@ -545,7 +561,7 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
 
       const int rbase = A + 3 * n - 4;                 // slab row of window slot 0
 #ifndef WDPM_ABLATE_COMPUTE                            /* timing experiments only: memory pattern alone */
-      three_stages<MODULE, SZ_SAFE, NSTAGES>(W, D, rbase, g.dr, cdr, ds);
+      three_stages<MODULE, SZ_SAFE, NSTAGES, PLAIN>(W, D, rbase, g.dr, cdr, ds);
 #else
 #pragma unroll
       for (int j = 0; j < 3; j++) W[0][j] += D[0][j] + D[1][j] + D[2][j];   // keep the dem loads alive
@@ -651,14 +667,14 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
 // ---------------------------------------------------------------------------------------------
 /* NB independent 3x3 blocks of one colour pass, advanced in lockstep (non-outlet form; block b is
  * w[b][row][col] with the centre at [1][1], neighbours in row-major order) */
-template <int MODULE, int NB>
+template <int MODULE, int NB, bool PLAIN = false>
 __device__ __forceinline__ void blocks_lockstep(double (&w)[NB][3][3], const double (&d)[NB][3][3]) {
   double wc[NB], dce[NB];
   bool gate[NB];
 #pragma unroll
   for (int b = 0; b < NB; b++) {
     wc[b] = w[b][1][1];
-    gate[b] = (wc[b] > 0.0) & (d[b][1][1] < WDPM_INF);             // WDPMCL.c:1099
+    gate[b] = PLAIN || ((wc[b] > 0.0) & (d[b][1][1] < WDPM_INF));  // WDPMCL.c:1099 (PLAIN: see block_update)
     dce[b] = gate[b] ? d[b][1][1] : -WDPM_INF;                      // see flow_add_nz / flow_drain_nz
     if (MODULE == 2) wc[b] = gate[b] ? wc[b] : 0.0;
   }
@@ -677,7 +693,7 @@ __device__ __forceinline__ void blocks_lockstep(double (&w)[NB][3][3], const dou
 
 /* one row alignment (three column alignments oj = 1,2,3) on the NB row blocks at window slots
  * S0 + 3b .. S0 + 3b + 2 of a window of NR rows; the lockstep twin of stage_impl */
-template <int MODULE, int NB, int S0, int NR>
+template <int MODULE, int NB, int S0, int NR, bool PLAIN = false>
 __device__ __forceinline__ void stage_lockstep(double (&W)[NR][3], const double (&D)[NR][3]) {
   double w[NB][3][3], d[NB][3][3];
   double n0[NB][3], n1[NB][3], e0[NB][3], e1[NB][3];      // columns 0 and 1 of the next lane: water, elevation
@@ -688,7 +704,7 @@ __device__ __forceinline__ void stage_lockstep(double (&W)[NR][3], const double 
     for (int r = 0; r < 3; r++)
 #pragma unroll
       for (int c = 0; c < 3; c++) { w[b][r][c] = W[S0 + 3 * b + r][c]; d[b][r][c] = D[S0 + 3 * b + r][c]; }
-  blocks_lockstep<MODULE, NB>(w, d);
+  blocks_lockstep<MODULE, NB, PLAIN>(w, d);
   // oj = 2: own columns 1,2 + column 0 of the next lane
 #pragma unroll
   for (int b = 0; b < NB; b++)
@@ -700,7 +716,7 @@ __device__ __forceinline__ void stage_lockstep(double (&W)[NR][3], const double 
       w[b][r][0] = w[b][r][1]; w[b][r][1] = w[b][r][2]; w[b][r][2] = n0[b][r];
       d[b][r][0] = d[b][r][1]; d[b][r][1] = d[b][r][2]; d[b][r][2] = e0[b][r];
     }
-  blocks_lockstep<MODULE, NB>(w, d);
+  blocks_lockstep<MODULE, NB, PLAIN>(w, d);
   // oj = 3: own column 2 + columns 0,1 of the next lane
 #pragma unroll
   for (int b = 0; b < NB; b++)
@@ -711,7 +727,7 @@ __device__ __forceinline__ void stage_lockstep(double (&W)[NR][3], const double 
       w[b][r][0] = w[b][r][1]; w[b][r][1] = w[b][r][2]; w[b][r][2] = n1[b][r];
       d[b][r][0] = d[b][r][1]; d[b][r][1] = d[b][r][2]; d[b][r][2] = e1[b][r];
     }
-  blocks_lockstep<MODULE, NB>(w, d);
+  blocks_lockstep<MODULE, NB, PLAIN>(w, d);
   // own column 2 back into the window; the borrowed columns back to lane+1 (lane 0 keeps its own)
 #pragma unroll
   for (int b = 0; b < NB; b++)
@@ -723,7 +739,7 @@ __device__ __forceinline__ void stage_lockstep(double (&W)[NR][3], const double 
     }
 }
 
-template <int MODULE, bool FLUSH, int K = 1>
+template <int MODULE, bool FLUSH, int K = 1, bool PLAIN = false>
 __global__ void __launch_bounds__(256, 2)
 tri_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout, const double *__restrict__ dem,
                      const SlabGeom g, const int nstrips, const int nitems, const int A0, const int out_last,
@@ -899,9 +915,9 @@ tri_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout, 
     }
   }
   if (!outlet_here) {
-    stage_lockstep<MODULE, K + 2, 0, NR>(W, D);   // oi = 1 on rows 0-2, 3-5, 6-8 (, 9-11)
-    stage_lockstep<MODULE, K + 1, 1, NR>(W, D);   // oi = 2 on rows 1-3, 4-6 (, 7-9)
-    stage_lockstep<MODULE, K, 2, NR>(W, D);       // oi = 3 on rows 2-4 (, 5-7)
+    stage_lockstep<MODULE, K + 2, 0, NR, PLAIN>(W, D);   // oi = 1 on rows 0-2, 3-5, 6-8 (, 9-11)
+    stage_lockstep<MODULE, K + 1, 1, NR, PLAIN>(W, D);   // oi = 2 on rows 1-3, 4-6 (, 7-9)
+    stage_lockstep<MODULE, K, 2, NR, PLAIN>(W, D);       // oi = 3 on rows 2-4 (, 5-7)
   }
 
   // rows or_lo .. or_hi, columns oc_lo .. oc_hi (slots 0 and 1 only for the raster's first rows)
@@ -993,17 +1009,24 @@ static hipError_t dpp_selfcheck(hipStream_t s) {
 
 hipError_t wdpm_launch_fused(int module, const double *w_in, double *w_out, const double *dem, const DemCode &code,
                              const SlabGeom &g, int chunk_rows, int signed_zero_safe, const double *flush,
-                             int drain_owed, double *totaldrain, hipStream_t s, TilePlan *tiles, const MaxDiffArgs *md) {
+                             int drain_owed, double *totaldrain, hipStream_t s, TilePlan *tiles, const MaxDiffArgs *md,
+                             int plain_water) {
   return wdpm_launch_fused_rows(module, w_in, w_out, dem, code, g, 0, g.rows - 1, chunk_rows, signed_zero_safe, flush,
-                                drain_owed, totaldrain, s, tiles, md);
+                                drain_owed, totaldrain, s, tiles, md, 0, plain_water);
 }
 
 /* one iteration restricted to the output rows [A0 + 2 (0 when A0 == 0), out_last]; A0 % 3 == 0 */
 hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out, const double *dem,
                                   const DemCode &code, const SlabGeom &g, int A0, int out_last, int chunk_rows,
                                   int signed_zero_safe, const double *flush, int drain_owed, double *totaldrain,
-                                  hipStream_t s, TilePlan *tiles, const MaxDiffArgs *md, int leave_cus) {
+                                  hipStream_t s, TilePlan *tiles, const MaxDiffArgs *md, int leave_cus, int plain_water) {
   if (tiles) tiles->maintained = 0;
+  /* The gate-free variants (PLAIN, see block_update) exist for the launches between a block's first (flush on load) and last
+   * (max diff) - of the drain module, which is bound by instruction issue (+4.5 % at 8192^2, +3.8 % at 4096^2), and of the
+   * triangle kernel (+3 % at 482^2).  The marching add / subtract kernel keeps its gate: 35 of 1001 instructions per step
+   * less changed nothing at 16384^2 and 8192^2 and cost 1 % at 4096^2 (profiles/r03/plain_water_ab.txt; DESIGN.md §4.1: that
+   * launch is bound by the memory system and by instruction issue alike). */
+  const bool plain = plain_water && !signed_zero_safe && !flush && !(md && md->old);
   const bool fold_md = md && md->old && module != 2 && !signed_zero_safe;
   if (md && md->old && !fold_md) return hipErrorInvalidValue;     /* the caller asks only where a folding variant exists */
   hipError_t e = dpp_selfcheck(s);
@@ -1050,9 +1073,9 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
       }
       const dim3 tgrid(((unsigned)((items + 3) / 4) + 7) / 8 * 8), tblock(256);
 #define WDPM_TRI_LAUNCH(...) hipLaunchKernelGGL((tri_iteration_kernel<__VA_ARGS__>), tgrid, tblock, 0, s, w_in, w_out, dem, g, nstr, (int)items, A0, out_last, totaldrain, thres, module == 2 ? drain_owed : 0)
-      if (module == 2) { if (flush) WDPM_TRI_LAUNCH(2, true); else WDPM_TRI_LAUNCH(2, false); }
-      else if (two) { if (flush) WDPM_TRI_LAUNCH(0, true, 2); else WDPM_TRI_LAUNCH(0, false, 2); }
-      else { if (flush) WDPM_TRI_LAUNCH(0, true); else WDPM_TRI_LAUNCH(0, false); }
+      if (module == 2) { if (flush) WDPM_TRI_LAUNCH(2, true); else if (plain) WDPM_TRI_LAUNCH(2, false, 1, true); else WDPM_TRI_LAUNCH(2, false); }
+      else if (two) { if (flush) WDPM_TRI_LAUNCH(0, true, 2); else if (plain) WDPM_TRI_LAUNCH(0, false, 2, true); else WDPM_TRI_LAUNCH(0, false, 2); }
+      else { if (flush) WDPM_TRI_LAUNCH(0, true); else if (plain) WDPM_TRI_LAUNCH(0, false, 1, true); else WDPM_TRI_LAUNCH(0, false); }
 #undef WDPM_TRI_LAUNCH
       return hipGetLastError();
     }
@@ -1128,7 +1151,8 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
 #define WDPM_LAUNCH(...) hipLaunchKernelGGL((fused_iteration_kernel<__VA_ARGS__>), grid, block, 0, s, w_in, w_out, dem, code, g, nstrips, nitems, H, A0, out_last, totaldrain, thres, module == 2 ? drain_owed : 0, tf, mda)
 #define WDPM_LAUNCH_FM(M, Z, D32) do { if (fold_md) { if (flush) WDPM_LAUNCH(M, Z, D32, true, true); else WDPM_LAUNCH(M, Z, D32, false, true); } \
                                        else { if (flush) WDPM_LAUNCH(M, Z, D32, true, false); else WDPM_LAUNCH(M, Z, D32, false, false); } } while (0)
-  if (module == 2 && fast) { if (flush) WDPM_LAUNCH(2, false, false, true, false); else WDPM_LAUNCH(2, false, false, false, false); }
+  if (module == 2 && fast && plain) WDPM_LAUNCH(2, false, false, false, false, true);
+  else if (module == 2 && fast) { if (flush) WDPM_LAUNCH(2, false, false, true, false); else WDPM_LAUNCH(2, false, false, false, false); }
   else if (module == 2) WDPM_LAUNCH(2, true, false, false, false);
   else if (dem32) WDPM_LAUNCH_FM(0, false, true);
   else if (fast) WDPM_LAUNCH_FM(0, false, false);

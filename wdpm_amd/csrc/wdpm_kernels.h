@@ -100,17 +100,25 @@ hipError_t wdpm_launch_pass(int module, double *w, const double *dem, const Slab
 hipError_t wdpm_launch_fused(int module, const double *w_in, double *w_out, const double *dem, const DemCode &code,
                              const SlabGeom &g, int chunk_rows, int signed_zero_safe, const double *flush,
                              int drain_owed, double *totaldrain, hipStream_t s, TilePlan *tiles = nullptr,
-                             const MaxDiffArgs *md = nullptr);
+                             const MaxDiffArgs *md = nullptr, int plain_water = 0);
 hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out, const double *dem,
                                   const DemCode &code, const SlabGeom &g, int A0, int out_last, int chunk_rows,
                                   int signed_zero_safe, const double *flush, int drain_owed, double *totaldrain,
                                   hipStream_t s, TilePlan *tiles = nullptr, const MaxDiffArgs *md = nullptr,
-                                  int leave_cus = 0);
+                                  int leave_cus = 0, int plain_water = 0);
+/* plain_water: the caller knows (wdpm_launch_scan_water, and nothing written since that could change it) that every cell of
+ * w_in that may not give water holds +0.0: launches that have such a variant then run without the centre gate */
 /* leave_cus: size the launch as if the chip had that many compute units fewer - the interior launch of an overlapped
  * iteration leaves room for the RCCL send/recv kernels queued beside it (a launch otherwise fills every slot for its
  * whole duration, and the transfer would start only when the first waves retire) */
-/* *flag |= 1 if any of the n doubles at p is -0.0 */
-hipError_t wdpm_launch_scan_negzero(const double *p, size_t n, unsigned long long *flag, hipStream_t s);
+/* What kinds of depth do the n cells at p hold (dem: the device DEM of the same cells, NODATA = +inf)?
+ *   *flag |= 1  a -0.0                       (the exact-zero stencil variant must run, see signed_zero_safe)
+ *   *flag |= 2  a negative depth             (gone once a threshold flush with thres >= 0 has been applied)
+ *   *flag |= 4  NaN, a depth above 1e290, or water on a NODATA cell   (stays)
+ * With none of them, every cell that may not give water (dry, NODATA, outside the slab) holds +0.0 exactly - and then
+ * the centre gate of the reference's sweep (WDPMCL.c:1099) needs no instructions: see PLAIN in wdpm_fused.hip. */
+enum { WDPM_WATER_NEGZERO = 1, WDPM_WATER_NEGATIVE = 2, WDPM_WATER_ODD = 4 };
+hipError_t wdpm_launch_scan_water(const double *p, const double *dem, size_t n, unsigned long long *flag, hipStream_t s);
 /* drain() (WDPMCL.c:1859-1897) on the device */
 hipError_t wdpm_launch_drain_outlet(double *w, const double *dem, const SlabGeom &g, double *totaldrain,
                                     hipStream_t s);

@@ -300,19 +300,26 @@ hipError_t wdpm_launch_seqsum_b(const double *w, const double *dem, size_t n, co
 // does the raster hold a negative zero?  (decides which add/subtract stencil variant is exact)
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-scan_negzero_kernel(const double *__restrict__ p, size_t n, unsigned long long *flag) {
+scan_water_kernel(const double *__restrict__ p, const double *__restrict__ dem, size_t n, unsigned long long *flag) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  bool hit = false;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-    hit |= (unsigned long long)__double_as_longlong(p[i]) == 0x8000000000000000ull;
-  if (__ballot(hit) && (threadIdx.x & 63) == 0) atomicOr(flag, 1ull);
+  unsigned hit = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const double w = p[i];
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(w);
+    if (bits == 0x8000000000000000ull) hit |= 1u;                       // -0.0
+    else if (w < 0.0) hit |= 2u;                                         // negative: gone after a flush with a threshold >= 0
+    else if (!(w <= 1e290) || (w > 0.0 && !(dem[i] < __builtin_inf()))) hit |= 4u;   // NaN, absurdly large, or water on a NODATA cell
+  }
+#pragma unroll
+  for (unsigned b = 1; b <= 4; b <<= 1)
+    if (__ballot((hit & b) != 0) && (threadIdx.x & 63) == 0) atomicOr(flag, (unsigned long long)b);
 }
 
-hipError_t wdpm_launch_scan_negzero(const double *p, size_t n, unsigned long long *flag, hipStream_t s) {
+hipError_t wdpm_launch_scan_water(const double *p, const double *dem, size_t n, unsigned long long *flag, hipStream_t s) {
   if (n == 0) return hipSuccess;
   size_t blocks = (n + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(scan_negzero_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, n, flag);
+  hipLaunchKernelGGL(scan_water_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, dem, n, flag);
   return hipGetLastError();
 }
 

@@ -274,16 +274,16 @@ int wdpm_rank_info(wdpm_rank *r, int32_t *halo, int32_t *exchange_every, int32_t
   return 0;
 }
 
-/* a -0.0 depth anywhere in the raster makes every rank use the sign-preserving stencil variant (halo
- * rows are written straight into device memory by the transport, past the library's own upload scan) */
+/* What kinds of depth the raster holds (a -0.0 anywhere, negative depths, odd values: WDPM_OPT_WATER_KINDS) decides which
+ * stencil variant runs, and halo rows are written straight into device memory by the transport, past the library's own
+ * upload scan: every rank takes the OR over all ranks */
 static int agree_on_options(wdpm_rank *r) {
   int64_t v = 0;
-  if (wdpm_get_option(r->c, WDPM_OPT_SIGNED_ZERO_SAFE, &v)) return 1;
+  if (wdpm_get_option(r->c, WDPM_OPT_WATER_KINDS, &v)) return 1;
   double mine = (double)v, all[MAXR];
   if (rank_allgather(r, &mine, 1, all)) return 1;
-  for (int q = 0; q < r->n; q++)
-    if (all[q] != 0.0) v = 1;
-  return wdpm_set_option(r->c, WDPM_OPT_SIGNED_ZERO_SAFE, v);
+  for (int q = 0; q < r->n; q++) v |= (int64_t)all[q];
+  return wdpm_set_option(r->c, WDPM_OPT_WATER_KINDS, v);
 }
 
 int wdpm_rank_upload(wdpm_rank *r, const double *slab_dem, const double *slab_water) {
@@ -385,9 +385,10 @@ static int rank_iterate(wdpm_rank *r, int32_t n_iter, int block_end) {
       owned_rows(r, &lo, &hi);
       if (wdpm_expect_max_diff(r->c, lo, hi)) return 1;
     }
-    if (r->overlap && step == room) {
-      /* this step ends a group of k and an exchange follows: produce the rows the neighbours need
-       * first, so that the transfer overlaps the interior rows of the last iteration */
+    if (r->overlap && (step == room || (block_end && done + step == n_iter))) {
+      /* this step ends a group of k - or the block, whose max diff starts from refreshed halos - and an exchange
+       * follows: produce the rows the neighbours need first, so that the transfer overlaps the interior rows of
+       * the last iteration */
       if (wdpm_iterate_overlapped(r->c, step, r->top_rows, r->bottom_rows)) return 1;
     } else if (wdpm_iterate(r->c, step)) {
       return 1;
