@@ -20,7 +20,9 @@
  * So the data path is the product's own (communicator set-up from an id, op lists, row offsets, streams,
  * tile-flag and max-diff bookkeeping around a refresh, the overlapped last iteration with a communicator attached,
  * the block scalars through ncclAllGather); only the wire is faked.
- * Fault injection for the product's deadlines (tests/test_mock_rccl.py): MOCK_RCCL_HANG_INIT_RANK=<r> makes that
+ * Fault injection (tests/test_mock_rccl.py) - a rank of a thread group that dies between collectives: MOCK_RCCL_FAIL_RANK=<r>
+ * with MOCK_RCCL_FAIL_AFTER=<n> makes that rank's (n+1)-th transfer fail before anything is posted; the product must then end
+ * every rank's communicator (ncclCommAbort wakes whoever waits here) and fail, not hang.  For the product's deadlines: MOCK_RCCL_HANG_INIT_RANK=<r> makes that
  * rank's ncclCommInitRank sleep MOCK_RCCL_HANG_S seconds (default 30) before failing; MOCK_RCCL_STALL_RECV_S=<s>
  * makes the FIRST receive of every rank return at once with the stream blocked for s seconds by a host function
  * (a transfer that never completes, as seen from the host), bounded so that nothing can hang the box.
@@ -52,6 +54,8 @@ struct World {
   std::mutex mu;
   std::condition_variable cv;
   std::vector<Post> box;                 // [src * n + dst]
+  bool dead = false;                     // ncclCommAbort on any rank: everybody's waits end with an error
+  int group_ends = 0;                    // fault injection: MOCK_RCCL_FAIL_AFTER counts rank MOCK_RCCL_FAIL_RANK's groups
 };
 
 // ---- one process per rank ------------------------------------------------------------------------------------
@@ -147,12 +151,20 @@ static void *map_handle(Proc *p, const hipIpcMemHandle_t &h) {
 static ncclResult_t group_end_threads(ncclComm *c) {
   World *w = c->w;
   ncclResult_t rc = ncclSuccess;
+  {
+    // fault injection: this rank's (n+1)-th transfer fails before anything is posted - a rank that dies between collectives
+    const int fail_rank = (int)env_num("MOCK_RCCL_FAIL_RANK", -1.0), fail_after = (int)env_num("MOCK_RCCL_FAIL_AFTER", -1.0);
+    std::unique_lock<std::mutex> lk(w->mu);
+    if (w->dead) return ncclSystemError;
+    if (c->rank == fail_rank && fail_after >= 0 && w->group_ends++ >= fail_after) return ncclSystemError;
+  }
   // post every send: "my rows are produced once this event fires"
   for (const Op &o : t_ops)
     if (o.send) {
       std::unique_lock<std::mutex> lk(w->mu);
       Post &p = w->box[(size_t)c->rank * w->n + o.peer];
-      w->cv.wait(lk, [&] { return !p.posted; });                 // the previous message of this pair was taken
+      w->cv.wait(lk, [&] { return !p.posted || w->dead; });      // the previous message of this pair was taken
+      if (w->dead) return ncclSystemError;
       if (hipEventRecord(p.ready, o.stream) != hipSuccess) rc = ncclUnhandledCudaError;
       p.buf = o.buf; p.bytes = o.bytes; p.posted = true; p.taken = false;
       w->cv.notify_all();
@@ -162,7 +174,8 @@ static ncclResult_t group_end_threads(ncclComm *c) {
     if (!o.send) {
       std::unique_lock<std::mutex> lk(w->mu);
       Post &p = w->box[(size_t)o.peer * w->n + c->rank];
-      w->cv.wait(lk, [&] { return p.posted && !p.taken; });
+      w->cv.wait(lk, [&] { return (p.posted && !p.taken) || w->dead; });
+      if (w->dead) return ncclSystemError;
       if (p.bytes != o.bytes) rc = ncclInvalidArgument;          // send / recv sizes must match, as with the real thing
       if (hipStreamWaitEvent(o.stream, p.ready, 0) != hipSuccess) rc = ncclUnhandledCudaError;
       if (hipMemcpyAsync(o.buf, p.buf, o.bytes < p.bytes ? o.bytes : p.bytes, hipMemcpyDeviceToDevice, o.stream) != hipSuccess)
@@ -176,7 +189,8 @@ static ncclResult_t group_end_threads(ncclComm *c) {
     if (o.send) {
       std::unique_lock<std::mutex> lk(w->mu);
       Post &p = w->box[(size_t)c->rank * w->n + o.peer];
-      w->cv.wait(lk, [&] { return p.taken; });
+      w->cv.wait(lk, [&] { return p.taken || w->dead; });
+      if (w->dead) return ncclSystemError;
       if (hipStreamWaitEvent(o.stream, p.copied, 0) != hipSuccess) rc = ncclUnhandledCudaError;
       p.posted = false;
       w->cv.notify_all();
@@ -339,6 +353,12 @@ ncclResult_t ncclCommDestroy(ncclComm_t c) {   // the World leaks: a test proces
 }
 ncclResult_t ncclCommAbort(ncclComm_t c) {
   if (c->proc) c->proc->sh->dead.store(1, std::memory_order_release);   // everybody's bounded waits end now
+  if (c->w) {                                                           // ranks of one process: wake whoever waits for a post
+    std::unique_lock<std::mutex> lk(c->w->mu);
+    c->w->dead = true;
+    c->w->cv.notify_all();
+    return ncclSuccess;                  // (the communicator object stays: another rank thread may be inside a call with it)
+  }
   return ncclCommDestroy(c);
 }
 ncclResult_t ncclCommCount(const ncclComm_t c, int *n) { *n = c->n; return ncclSuccess; }

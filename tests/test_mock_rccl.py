@@ -54,6 +54,26 @@ def test_cli_on_three_slabs_with_rccl_halos(mock_env, tmp_path):
     assert file_sha(os.path.join(tmp_path, "a300.asc")) == g["out_sha256"]
 
 
+def test_a_rank_that_fails_between_collectives_ends_the_run(mock_env, tmp_path):
+    """one rank of a thread group (WDPMCL with WDPM_DEVICES=0,0,0) fails at its third halo transfer.  The others
+    have matching receives queued whose sender will never post: the failing rank ends every communicator (wdpm_comm_abort),
+    their waits return, and the command exits non-zero with the reason - within seconds, where it used to hang for ever"""
+    import gzip
+    import time
+    from conftest import GOLDEN
+    from test_cli import HIP_CLI
+    with gzip.open(os.path.join(GOLDEN, "basin5.asc.gz"), "rb") as f:
+        (tmp_path / "basin5.asc").write_bytes(f.read())
+    env = dict(mock_env, WDPM_DEVICES="0,0,0", WDPM_EXCHANGE_EVERY="3", MOCK_RCCL_FAIL_RANK="1", MOCK_RCCL_FAIL_AFTER="2",
+               WDPM_SYNC_TIMEOUT_S="20")
+    t = time.time()
+    p = subprocess.run([HIP_CLI, "add", "basin5.asc", "NULL", "out.asc", "NULL", "100", "1.0", "1.0", "1", "1", "0.005", "2000"],
+                       cwd=tmp_path, capture_output=True, text=True, timeout=120, env=env)
+    assert p.returncode not in (0, 42), p.stdout[-500:] + p.stderr[-1500:]
+    assert "mock RCCL error" in p.stderr or "aborted" in p.stderr, p.stderr[-1500:]
+    assert time.time() - t < 60 and not os.path.exists(tmp_path / "out.asc")
+
+
 # ---- one process per rank ---------------------------------------------------------------------------------------
 @pytest.fixture(scope="module")
 def proc_env(mock_env):
