@@ -739,11 +739,12 @@ __device__ __forceinline__ void stage_lockstep(double (&W)[NR][3], const double 
     }
 }
 
-template <int MODULE, bool FLUSH, int K = 1, bool PLAIN = false>
+template <int MODULE, bool FLUSH, int K = 1, bool PLAIN = false, bool MD = false>
 __global__ void __launch_bounds__(256, 2)
 tri_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout, const double *__restrict__ dem,
                      const SlabGeom g, const int nstrips, const int nitems, const int A0, const int out_last,
-                     double *__restrict__ totaldrain, const double thres, const int drain_owed) {
+                     double *__restrict__ totaldrain, const double thres, const int drain_owed, const MaxDiffArgs md) {
+  static_assert(!MD || (K == 1 && MODULE != 2), "the max-diff variant exists for three rows per wave, add / subtract");
   // K row blocks out per wave: 3K + 6 rows in, oi = 1 on K + 2 row blocks, oi = 2 on K + 1, oi = 3 on K.  K = 1 is the kernel
   // described above; K = 2 (add / subtract only) does 9 block stages for six rows instead of 12 - for rasters whose waves no
   // longer fit on the chip in one round, where the launch is bound by instruction issue, not by a single wave's latency.
@@ -804,6 +805,18 @@ tri_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout, 
     for (int j = 0; j < 3; j++) {
       W[i][j] = *reinterpret_cast<const double *>(bw + voff[j]);
       D[i][j] = *reinterpret_cast<const double *>(bd + voff[j]);
+    }
+  }
+  // MD (round 3): the block's last launch of a small raster stays with this kernel - the snapshot's rows behind the rows this
+  // wave will store, requested with the window (the snapshot may still be owed the block's flush: applied as it is compared)
+  double O[3 * K + 2][3];
+  if (MD) {
+#pragma unroll
+    for (int i = 0; i < 3 * K + 2; i++) {
+      const int rc = A + i < g.rows ? A + i : g.rows - 1;
+      const char *bo = reinterpret_cast<const char *>(md.old + (size_t)rc * pitch);
+#pragma unroll
+      for (int j = 0; j < 3; j++) O[i][j] = *reinterpret_cast<const double *>(bo + voff[j]);
     }
   }
   if (FLUSH) {
@@ -932,6 +945,31 @@ tri_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout, 
     }
   }
   if (MODULE == 2 && owner && lane == 0) *totaldrain = ds.td;
+  if (MD) {
+    // max |w - oldw| over the cells this wave stored, of the rows asked for, with bigdem > missingvalue - plus the reference's
+    // seed cell [0][0] (WDPMCL.c:1239-1254); `if (d > m)` per lane, wave maximum, one atomicMax
+    double md_max = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3 * K + 2; i++) {
+      const int r = A + i;
+      const bool row_in = r >= or_lo && r <= or_hi && r >= md.row_lo && r < md.row_hi;           // wave-uniform
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        const int c = colb + j;
+        double o = O[i][j];
+        o = o < md.thres ? 0.0 : o;                                                               // :1059-1062
+        const double dd = __builtin_fabs(W[i][j] - o);                                            // :1241
+        const bool cell = row_in & (c >= oc_lo) & (c <= oc_hi) & ((D[i][j] < WDPM_INF) | ((r == 0) & (c == 0)));
+        md_max = (cell & (dd > md_max)) ? dd : md_max;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const double o = __shfl_xor(md_max, off, 64);
+      md_max = o > md_max ? o : md_max;
+    }
+    if (lane == 0 && md_max > 0.0) atomicMax(md.bits, (unsigned long long)__double_as_longlong(md_max));
+  }
 }
 
 __global__ void dpp_probe_kernel(int *out) {
@@ -1062,18 +1100,22 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
     const bool wide = !tiles || tiles->wide_tri_ok;
     const long long slots_now = tri_slots.load(std::memory_order_relaxed);
     const long long tri_limit = wide ? slots_now * 27 / 10 : slots_now;
-    if (env_tri && !signed_zero_safe && !fold_md && chunk_rows < 3 && (items <= tri_limit || env_tri == 2)) {
-      // more than one round of waves: the launch is bound by instruction issue, and six rows per wave (K = 2: 9 block stages
-      // instead of 12 for them) are the cheaper way through; one round: three rows per wave is the shorter critical path
-      const bool two = module != 2 && (env_k == 2 || (env_k == 0 && items > slots_now));
+    // more than one round of waves: the launch is bound by instruction issue, and six rows per wave (K = 2: 9 block stages
+    // instead of 12 for them) are the cheaper way through; one round: three rows per wave is the shorter critical path
+    const bool two = module != 2 && (env_k == 2 || (env_k == 0 && items > slots_now));
+    // the block's last launch (max diff folded in) stays here where three rows per wave do (round 3); six-row waves have no
+    // registers left for the snapshot's rows: those launches go to the marching kernel as before
+    if (env_tri && !signed_zero_safe && !(fold_md && two) && chunk_rows < 3 && (items <= tri_limit || env_tri == 2)) {
       if (two) {
         nch = (out_last - A0 - 1 + 5) / 6;
         if (nch < 1) nch = 1;
         items = (long long)nstr * nch;
       }
       const dim3 tgrid(((unsigned)((items + 3) / 4) + 7) / 8 * 8), tblock(256);
-#define WDPM_TRI_LAUNCH(...) hipLaunchKernelGGL((tri_iteration_kernel<__VA_ARGS__>), tgrid, tblock, 0, s, w_in, w_out, dem, g, nstr, (int)items, A0, out_last, totaldrain, thres, module == 2 ? drain_owed : 0)
-      if (module == 2) { if (flush) WDPM_TRI_LAUNCH(2, true); else if (plain) WDPM_TRI_LAUNCH(2, false, 1, true); else WDPM_TRI_LAUNCH(2, false); }
+      const MaxDiffArgs tmd = fold_md ? *md : MaxDiffArgs{nullptr, 0.0, 0, 0, nullptr};
+#define WDPM_TRI_LAUNCH(...) hipLaunchKernelGGL((tri_iteration_kernel<__VA_ARGS__>), tgrid, tblock, 0, s, w_in, w_out, dem, g, nstr, (int)items, A0, out_last, totaldrain, thres, module == 2 ? drain_owed : 0, tmd)
+      if (fold_md) { if (flush) WDPM_TRI_LAUNCH(0, true, 1, false, true); else WDPM_TRI_LAUNCH(0, false, 1, false, true); }
+      else if (module == 2) { if (flush) WDPM_TRI_LAUNCH(2, true); else if (plain) WDPM_TRI_LAUNCH(2, false, 1, true); else WDPM_TRI_LAUNCH(2, false); }
       else if (two) { if (flush) WDPM_TRI_LAUNCH(0, true, 2); else if (plain) WDPM_TRI_LAUNCH(0, false, 2, true); else WDPM_TRI_LAUNCH(0, false, 2); }
       else { if (flush) WDPM_TRI_LAUNCH(0, true); else if (plain) WDPM_TRI_LAUNCH(0, false, 1, true); else WDPM_TRI_LAUNCH(0, false); }
 #undef WDPM_TRI_LAUNCH
