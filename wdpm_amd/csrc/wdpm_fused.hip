@@ -972,6 +972,93 @@ tri_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout, 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Smallest rasters: the "relay" kernel (round 3).  A workgroup of four waves takes twelve rows of one strip and
+// produces the middle six; each wave carries ONE row block through a row alignment - a single dependent chain per lane, which
+// runs at its latency, where the triangle kernel's wave issues three, two, one blocks in lockstep and is bound by instruction
+// issue - and the rows two alignments share pass from wave to wave through LDS:
+//       oi = 1   wave w on rows 3w .. 3w+2                      (w = 0..3)
+//       row 3w+3 (wave w+1's first row) -> wave w               LDS + s_barrier
+//       oi = 2   wave w on rows 3w+1 .. 3w+3                    (w = 0..2)
+//       row 3w+4 (wave w+1's second row) -> wave w              LDS + s_barrier
+//       oi = 3   wave w on rows 3w+2 .. 3w+4, stored            (w = 0, 1)
+// Nine block stages for six rows, as in the six-row triangle wave, but three in a row per wave instead of nine.  Same trapezoid,
+// same pass order per cell, same arithmetic (stage_lockstep with one block): bit-identical.  Add / subtract only.
+// ---------------------------------------------------------------------------------------------
+template <bool FLUSH, bool PLAIN>
+__global__ void __launch_bounds__(256, 2)
+relay_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout, const double *__restrict__ dem,
+                       const SlabGeom g, const int nstrips, const int nwg, const int A0, const int out_last, const double thres) {
+  const int lane = threadIdx.x & 63;
+  const int vb = (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8;       // XCD-contiguous workgroups
+  if (vb >= nwg) return;                                                    // workgroup-uniform: nobody is left at a barrier
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int strip = vb % nstrips, chunk = vb / nstrips;
+  const int c0 = kStripOut * strip;
+  const int oc_lo = strip == 0 ? 0 : c0 + kHaloL;
+  int oc_hi = c0 + kStripIn - 1 - kHaloR;
+  if (oc_hi > g.ncp - 1) oc_hi = g.ncp - 1;
+  const int A = A0 + 6 * chunk;                   // the workgroup's rows A .. A+11; exact output rows A+2 .. A+7
+  const int or_lo = A == 0 ? 0 : A + 2;
+  int or_hi = A + 7;
+  if (or_hi > out_last) or_hi = out_last;
+  const int R0 = A + 3 * wave;                    // this wave's rows R0 .. R0+2, later up to R0+4
+  const int colb = c0 + 3 * lane;
+  const size_t pitch = (size_t)g.ncp;
+  unsigned voff[3];
+#pragma unroll
+  for (int j = 0; j < 3; j++) voff[j] = 8u * (unsigned)(colb + j < g.ncp ? colb + j : g.ncp - 1);
+  double W[5][3], D[5][3];
+#pragma unroll
+  for (int i = 0; i < 5; i++) {
+    const int rc = R0 + i < g.rows ? R0 + i : g.rows - 1;
+    const char *bw = reinterpret_cast<const char *>(win + (size_t)rc * pitch);
+    const char *bd = reinterpret_cast<const char *>(dem + (size_t)rc * pitch);
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      D[i][j] = *reinterpret_cast<const double *>(bd + voff[j]);
+      W[i][j] = i < 3 ? *reinterpret_cast<const double *>(bw + voff[j]) : 0.0;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 5; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      if (FLUSH && i < 3) W[i][j] = W[i][j] < thres ? 0.0 : W[i][j];               // WDPMCL.c:1059-1062
+      const bool ok = (R0 + i < g.rows) & (colb + j < g.ncp);                      // outside the slab: dem = +inf, water = 0
+      W[i][j] = ok ? W[i][j] : 0.0;
+      D[i][j] = ok ? D[i][j] : WDPM_INF;
+    }
+  __shared__ double xch[2][4][3 * kLanes];
+  stage_lockstep<0, 1, 0, 5, PLAIN>(W, D);                                   // oi = 1
+#pragma unroll
+  for (int j = 0; j < 3; j++) xch[0][wave][j * kLanes + lane] = W[0][j];
+  __syncthreads();
+  if (wave < 3) {
+#pragma unroll
+    for (int j = 0; j < 3; j++) W[3][j] = xch[0][wave + 1][j * kLanes + lane];
+    stage_lockstep<0, 1, 1, 5, PLAIN>(W, D);                                 // oi = 2
+  }
+#pragma unroll
+  for (int j = 0; j < 3; j++) xch[1][wave][j * kLanes + lane] = W[1][j];
+  __syncthreads();
+  if (wave >= 2) return;
+#pragma unroll
+  for (int j = 0; j < 3; j++) W[4][j] = xch[1][wave + 1][j * kLanes + lane];
+  stage_lockstep<0, 1, 2, 5, PLAIN>(W, D);                                   // oi = 3
+  // wave 0 stores rows A+2 .. A+4 (and rows 0, 1 of the raster's first chunk), wave 1 rows A+5 .. A+7
+#pragma unroll
+  for (int i = 0; i < 5; i++) {
+    const int r = R0 + i;
+    if (r < or_lo || r > or_hi || (i < 2 && !(wave == 0 && A == 0))) continue;    // wave-uniform
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const int c = colb + j;
+      if (c >= oc_lo && c <= oc_hi) __builtin_nontemporal_store(W[i][j], wout + (size_t)r * pitch + c);
+    }
+  }
+}
+
 __global__ void dpp_probe_kernel(int *out) {
   const int lane = threadIdx.x;
   const double v = (double)lane;
@@ -1102,6 +1189,23 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
     const long long tri_limit = wide ? slots_now * 27 / 10 : slots_now;
     // more than one round of waves: the launch is bound by instruction issue, and six rows per wave (K = 2: 9 block stages
     // instead of 12 for them) are the cheaper way through; one round: three rows per wave is the shorter critical path
+    {
+      // the relay kernel (four waves per six rows of a strip): 482^2 7.27 -> 5.25 us per iteration, 200^2 6.9 -> 5.0, where all
+      // its waves find a SIMD of their own; ahead of the triangle kernel up to two and a half rounds of waves at two per SIMD
+      // (700^2 10.1 -> 8.5, 1000^2 10.3 -> 9.5, 1200^2 a tie, 1600^2 behind: profiles/r03/relay_sweep.txt)
+      static std::atomic<int> env_relay{-1};
+      if (env_relay < 0) { const char *t = getenv("WDPM_RELAY"); env_relay = t ? atoi(t) : 1; }
+      const int nch6 = (out_last - A0 - 1 + 5) / 6 > 0 ? (out_last - A0 - 1 + 5) / 6 : 1;
+      const long long nwg = (long long)nstr * nch6;
+      if (env_relay && env_tri && module != 2 && !signed_zero_safe && !fold_md && chunk_rows < 3 &&
+          (nwg * 8 <= slots_now * 5 || env_relay == 2)) {    // slots_now counts two waves per SIMD
+        const dim3 rgrid(((unsigned)nwg + 7) / 8 * 8), rblock(256);
+#define WDPM_RELAY_LAUNCH(...) hipLaunchKernelGGL((relay_iteration_kernel<__VA_ARGS__>), rgrid, rblock, 0, s, w_in, w_out, dem, g, nstr, (int)nwg, A0, out_last, thres)
+        if (flush) WDPM_RELAY_LAUNCH(true, false); else if (plain) WDPM_RELAY_LAUNCH(false, true); else WDPM_RELAY_LAUNCH(false, false);
+#undef WDPM_RELAY_LAUNCH
+        return hipGetLastError();
+      }
+    }
     const bool two = module != 2 && (env_k == 2 || (env_k == 0 && items > slots_now));
     // the block's last launch (max diff folded in) stays here where three rows per wave do (round 3); six-row waves have no
     // registers left for the snapshot's rows: those launches go to the marching kernel as before
