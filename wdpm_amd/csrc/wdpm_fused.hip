@@ -983,12 +983,13 @@ tri_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout, 
 //       row 3w+4 (wave w+1's second row) -> wave w              LDS + s_barrier
 //       oi = 3   wave w on rows 3w+2 .. 3w+4, stored            (w = 0, 1)
 // Nine block stages for six rows, as in the six-row triangle wave, but three in a row per wave instead of nine.  Same trapezoid,
-// same pass order per cell, same arithmetic (stage_lockstep with one block): bit-identical.  Add / subtract only.
+// same pass order per cell, same arithmetic (stage_lockstep with one block): bit-identical.
 // ---------------------------------------------------------------------------------------------
-template <bool FLUSH, bool PLAIN>
+template <int MODULE, bool FLUSH, bool PLAIN>
 __global__ void __launch_bounds__(256, 2)
 relay_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout, const double *__restrict__ dem,
-                       const SlabGeom g, const int nstrips, const int nwg, const int A0, const int out_last, const double thres) {
+                       const SlabGeom g, const int nstrips, const int nwg, const int A0, const int out_last, const double thres,
+                       double *__restrict__ totaldrain, const int drain_owed) {
   const int lane = threadIdx.x & 63;
   const int vb = (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8;       // XCD-contiguous workgroups
   if (vb >= nwg) return;                                                    // workgroup-uniform: nobody is left at a barrier
@@ -1008,7 +1009,7 @@ relay_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
   unsigned voff[3];
 #pragma unroll
   for (int j = 0; j < 3; j++) voff[j] = 8u * (unsigned)(colb + j < g.ncp ? colb + j : g.ncp - 1);
-  double W[5][3], D[5][3];
+  double W[7][3], D[7][3];                        // slots 0 .. 4 are used (seven: stage_impl's window type)
 #pragma unroll
   for (int i = 0; i < 5; i++) {
     const int rc = R0 + i < g.rows ? R0 + i : g.rows - 1;
@@ -1021,6 +1022,54 @@ relay_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
     }
   }
 #pragma unroll
+  for (int j = 0; j < 3; j++) { W[5][j] = W[6][j] = 0.0; D[5][j] = D[6][j] = WDPM_INF; }
+
+  // Drain: totaldrain is carried from row alignment to row alignment by whichever wave holds the outlet's block (at most one
+  // per alignment and workgroup: wave-uniform arithmetic every wave can do), through LDS; the workgroup whose stored block
+  // holds the outlet has seen every pass that touches it, in the reference's order, and writes it back.
+  DrainState ds;
+  ds.td = 0.0;
+  ds.hit = false;
+  bool owner = false;
+  int wo[3] = {-1, -1, -1};                       // wave that holds the outlet's row in its block of alignment oi = 1, 2, 3
+  bool cdr[5];
+#pragma unroll
+  for (int j = 0; j < 5; j++) cdr[j] = MODULE == 2 && colb + j == g.dc;
+  if (MODULE == 2) {
+    const bool outlet_inside = g.dr >= 1 && g.dr <= g.rows - 2 && g.dc >= 1 && g.dc <= g.ncp - 2;
+    const bool col_here = g.dc >= c0 && g.dc <= c0 + kStripIn + 1;      // the strip and the two columns lane 63 borrows
+#pragma unroll
+    for (int st = 0; st < 3; st++) {
+      const int rel = g.dr - A - st;              // alignment st + 1: wave w on rows A + 3w + st .. + 2
+      if (col_here && rel >= 0 && rel / 3 <= 3 - st) wo[st] = rel / 3;
+    }
+    owner = g.dr >= or_lo && g.dr <= or_hi && g.dc >= oc_lo && g.dc <= oc_hi;
+    ds.td = *totaldrain;
+    if (drain_owed && outlet_inside) {
+      if (owner) {                                // the previous iteration's drain() (see fused_iteration_kernel): every wave of the
+        double sum = 0.0;                         // owning workgroup adds it up for itself
+#pragma unroll
+        for (int i = -1; i <= 1; i++)
+#pragma unroll
+          for (int j = -1; j <= 1; j++) {
+            const size_t k = (size_t)(g.dr + i) * g.ncp + (g.dc + j);
+            const double wk = win[k];
+            if (dem[k] < WDPM_INF && wk > 0) sum += wk;
+          }
+        ds.td = ds.td + sum;
+      }
+      if (R0 + 2 >= g.dr - 1 && R0 <= g.dr + 1) {                                   // wave-uniform, rare
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+          for (int j = 0; j < 3; j++) {
+            const int r = R0 + i, c = colb + j;
+            W[i][j] = (r >= g.dr - 1 && r <= g.dr + 1 && c >= g.dc - 1 && c <= g.dc + 1) ? 0.0 : W[i][j];   // :1885-1889
+          }
+      }
+    }
+  }
+#pragma unroll
   for (int i = 0; i < 5; i++)
 #pragma unroll
     for (int j = 0; j < 3; j++) {
@@ -1030,22 +1079,36 @@ relay_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
       D[i][j] = ok ? D[i][j] : WDPM_INF;
     }
   __shared__ double xch[2][4][3 * kLanes];
-  stage_lockstep<0, 1, 0, 5, PLAIN>(W, D);                                   // oi = 1
+  __shared__ double td_sh[3];
+  // one row alignment on this wave's block at slots S0 .. S0+2 (st = S0): the outlet's block takes block_update's outlet form
+#define WDPM_RELAY_STAGE(S0)                                                                               \
+  do {                                                                                                     \
+    if (MODULE == 2 && wo[S0] == wave) {                                                                   \
+      stage_impl<2, false, S0, true>(W, D, R0 + S0, g.dr, cdr, ds);                                        \
+      if (lane == 0) td_sh[S0] = ds.td;                                                                    \
+    } else {                                                                                               \
+      stage_lockstep<MODULE, 1, S0, 7, PLAIN>(W, D);                                                       \
+    }                                                                                                      \
+  } while (0)
+  WDPM_RELAY_STAGE(0);                                                        // oi = 1
 #pragma unroll
   for (int j = 0; j < 3; j++) xch[0][wave][j * kLanes + lane] = W[0][j];
   __syncthreads();
+  if (MODULE == 2 && wo[0] >= 0) ds.td = td_sh[0];
   if (wave < 3) {
 #pragma unroll
     for (int j = 0; j < 3; j++) W[3][j] = xch[0][wave + 1][j * kLanes + lane];
-    stage_lockstep<0, 1, 1, 5, PLAIN>(W, D);                                 // oi = 2
+    WDPM_RELAY_STAGE(1);                                                      // oi = 2
   }
 #pragma unroll
   for (int j = 0; j < 3; j++) xch[1][wave][j * kLanes + lane] = W[1][j];
   __syncthreads();
   if (wave >= 2) return;
+  if (MODULE == 2 && wo[1] >= 0) ds.td = td_sh[1];
 #pragma unroll
   for (int j = 0; j < 3; j++) W[4][j] = xch[1][wave + 1][j * kLanes + lane];
-  stage_lockstep<0, 1, 2, 5, PLAIN>(W, D);                                   // oi = 3
+  WDPM_RELAY_STAGE(2);                                                        // oi = 3
+#undef WDPM_RELAY_STAGE
   // wave 0 stores rows A+2 .. A+4 (and rows 0, 1 of the raster's first chunk), wave 1 rows A+5 .. A+7
 #pragma unroll
   for (int i = 0; i < 5; i++) {
@@ -1057,6 +1120,8 @@ relay_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
       if (c >= oc_lo && c <= oc_hi) __builtin_nontemporal_store(W[i][j], wout + (size_t)r * pitch + c);
     }
   }
+  // the wave that ran the last alignment's outlet block holds the final value; if that alignment had none here, wave 0 does
+  if (MODULE == 2 && owner && lane == 0 && wave == (wo[2] >= 0 ? wo[2] : 0)) *totaldrain = ds.td;
 }
 
 __global__ void dpp_probe_kernel(int *out) {
@@ -1189,24 +1254,37 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
     const long long tri_limit = wide ? slots_now * 27 / 10 : slots_now;
     // more than one round of waves: the launch is bound by instruction issue, and six rows per wave (K = 2: 9 block stages
     // instead of 12 for them) are the cheaper way through; one round: three rows per wave is the shorter critical path
+    const bool two = module != 2 && (env_k == 2 || (env_k == 0 && items > slots_now));
     {
-      // the relay kernel (four waves per six rows of a strip): 482^2 7.27 -> 5.25 us per iteration, 200^2 6.9 -> 5.0, where all
-      // its waves find a SIMD of their own; ahead of the triangle kernel up to two and a half rounds of waves at two per SIMD
-      // (700^2 10.1 -> 8.5, 1000^2 10.3 -> 9.5, 1200^2 a tie, 1600^2 behind: profiles/r03/relay_sweep.txt)
+      // the relay kernel (four waves per six rows of a strip): add 482^2 7.3 -> 5.25 us per iteration, 700^2 10.0 -> 8.4,
+      // 1000^2 10.4 -> 9.6; drain 482^2 12.0 -> 8.3, 1000^2 16.6 -> 12.9, 1600^2 34.7 -> 29.8 (profiles/r03/relay_sweep.txt)
       static std::atomic<int> env_relay{-1};
       if (env_relay < 0) { const char *t = getenv("WDPM_RELAY"); env_relay = t ? atoi(t) : 1; }
       const int nch6 = (out_last - A0 - 1 + 5) / 6 > 0 ? (out_last - A0 - 1 + 5) / 6 : 1;
       const long long nwg = (long long)nstr * nch6;
-      if (env_relay && env_tri && module != 2 && !signed_zero_safe && !fold_md && chunk_rows < 3 &&
-          (nwg * 8 <= slots_now * 5 || env_relay == 2)) {    // slots_now counts two waves per SIMD
+      static std::atomic<int> simds{0};
+      if (!simds) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        simds = 4 * cus;
+      }
+      // Up to one wave per SIMD: always.  Beyond that, up to 6.5 waves per SIMD for add / subtract and 18 for drain (where the
+      // sweeps break even: add 1200^2 14.2 against 14.9 us, 1600^2 behind; drain 2000^2 40.6 against 44.1, 2400^2 behind) - where
+      // the triangle kernel would run in one round anyway, or the raster is known to be mostly wet: like the triangle kernel this
+      // one keeps no dry-tile flags (see `wide` above)
+      const long long nsimd = simds.load(std::memory_order_relaxed), waves4 = nwg * 4;
+      const long long deep = module == 2 ? 18 * nsimd : 13 * nsimd / 2;
+      const bool relay_ok = env_tri && !signed_zero_safe && chunk_rows < 3 &&
+                            (waves4 <= nsimd || ((wide || items <= slots_now) && waves4 <= deep) || env_relay == 2);
+      if (env_relay && !fold_md && relay_ok) {
         const dim3 rgrid(((unsigned)nwg + 7) / 8 * 8), rblock(256);
-#define WDPM_RELAY_LAUNCH(...) hipLaunchKernelGGL((relay_iteration_kernel<__VA_ARGS__>), rgrid, rblock, 0, s, w_in, w_out, dem, g, nstr, (int)nwg, A0, out_last, thres)
-        if (flush) WDPM_RELAY_LAUNCH(true, false); else if (plain) WDPM_RELAY_LAUNCH(false, true); else WDPM_RELAY_LAUNCH(false, false);
+#define WDPM_RELAY_LAUNCH(...) hipLaunchKernelGGL((relay_iteration_kernel<__VA_ARGS__>), rgrid, rblock, 0, s, w_in, w_out, dem, g, nstr, (int)nwg, A0, out_last, thres, totaldrain, module == 2 ? drain_owed : 0)
+        if (module == 2) { if (flush) WDPM_RELAY_LAUNCH(2, true, false); else if (plain) WDPM_RELAY_LAUNCH(2, false, true); else WDPM_RELAY_LAUNCH(2, false, false); }
+        else if (flush) WDPM_RELAY_LAUNCH(0, true, false); else if (plain) WDPM_RELAY_LAUNCH(0, false, true); else WDPM_RELAY_LAUNCH(0, false, false);
 #undef WDPM_RELAY_LAUNCH
         return hipGetLastError();
       }
     }
-    const bool two = module != 2 && (env_k == 2 || (env_k == 0 && items > slots_now));
     // the block's last launch (max diff folded in) stays here where three rows per wave do (round 3); six-row waves have no
     // registers left for the snapshot's rows: those launches go to the marching kernel as before
     if (env_tri && !signed_zero_safe && !(fold_md && two) && chunk_rows < 3 && (items <= tri_limit || env_tri == 2)) {
