@@ -985,8 +985,8 @@ tri_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout, 
 // Nine block stages for six rows, as in the six-row triangle wave, but three in a row per wave instead of nine.  Same trapezoid,
 // same pass order per cell, same arithmetic (stage_lockstep with one block): bit-identical.
 // ---------------------------------------------------------------------------------------------
-template <int MODULE, bool FLUSH, bool PLAIN>
-__global__ void __launch_bounds__(256, 2)
+template <int MODULE, bool FLUSH, bool PLAIN, int NW = 4>
+__global__ void __launch_bounds__(64 * NW, 2)
 relay_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout, const double *__restrict__ dem,
                        const SlabGeom g, const int nstrips, const int nwg, const int A0, const int out_last, const double thres,
                        double *__restrict__ totaldrain, const int drain_owed) {
@@ -999,9 +999,12 @@ relay_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
   const int oc_lo = strip == 0 ? 0 : c0 + kHaloL;
   int oc_hi = c0 + kStripIn - 1 - kHaloR;
   if (oc_hi > g.ncp - 1) oc_hi = g.ncp - 1;
-  const int A = A0 + 6 * chunk;                   // the workgroup's rows A .. A+11; exact output rows A+2 .. A+7
+  // NW waves: rows A .. A + 3 NW - 1 in, the middle 3 (NW - 2) out (NW = 4: twelve in, six out; NW = 8: 24 in, 18 out - fewer
+  // waves and less re-reading per row where the waves no longer fit on the chip at once)
+  constexpr int kOut = 3 * (NW - 2);
+  const int A = A0 + kOut * chunk;                // exact output rows A+2 .. A+kOut+1
   const int or_lo = A == 0 ? 0 : A + 2;
-  int or_hi = A + 7;
+  int or_hi = A + kOut + 1;
   if (or_hi > out_last) or_hi = out_last;
   const int R0 = A + 3 * wave;                    // this wave's rows R0 .. R0+2, later up to R0+4
   const int colb = c0 + 3 * lane;
@@ -1041,7 +1044,7 @@ relay_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
 #pragma unroll
     for (int st = 0; st < 3; st++) {
       const int rel = g.dr - A - st;              // alignment st + 1: wave w on rows A + 3w + st .. + 2
-      if (col_here && rel >= 0 && rel / 3 <= 3 - st) wo[st] = rel / 3;
+      if (col_here && rel >= 0 && rel / 3 <= NW - 1 - st) wo[st] = rel / 3;
     }
     owner = g.dr >= or_lo && g.dr <= or_hi && g.dc >= oc_lo && g.dc <= oc_hi;
     ds.td = *totaldrain;
@@ -1078,7 +1081,7 @@ relay_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
       W[i][j] = ok ? W[i][j] : 0.0;
       D[i][j] = ok ? D[i][j] : WDPM_INF;
     }
-  __shared__ double xch[2][4][3 * kLanes];
+  __shared__ double xch[2][NW][3 * kLanes];
   __shared__ double td_sh[3];
   // one row alignment on this wave's block at slots S0 .. S0+2 (st = S0): the outlet's block takes block_update's outlet form
 #define WDPM_RELAY_STAGE(S0)                                                                               \
@@ -1095,7 +1098,7 @@ relay_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
   for (int j = 0; j < 3; j++) xch[0][wave][j * kLanes + lane] = W[0][j];
   __syncthreads();
   if (MODULE == 2 && wo[0] >= 0) ds.td = td_sh[0];
-  if (wave < 3) {
+  if (wave < NW - 1) {
 #pragma unroll
     for (int j = 0; j < 3; j++) W[3][j] = xch[0][wave + 1][j * kLanes + lane];
     WDPM_RELAY_STAGE(1);                                                      // oi = 2
@@ -1103,13 +1106,13 @@ relay_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
 #pragma unroll
   for (int j = 0; j < 3; j++) xch[1][wave][j * kLanes + lane] = W[1][j];
   __syncthreads();
-  if (wave >= 2) return;
+  if (wave >= NW - 2) return;
   if (MODULE == 2 && wo[1] >= 0) ds.td = td_sh[1];
 #pragma unroll
   for (int j = 0; j < 3; j++) W[4][j] = xch[1][wave + 1][j * kLanes + lane];
   WDPM_RELAY_STAGE(2);                                                        // oi = 3
 #undef WDPM_RELAY_STAGE
-  // wave 0 stores rows A+2 .. A+4 (and rows 0, 1 of the raster's first chunk), wave 1 rows A+5 .. A+7
+  // wave w stores rows A+3w+2 .. A+3w+4 (wave 0 also rows 0, 1 of the raster's first chunk)
 #pragma unroll
   for (int i = 0; i < 5; i++) {
     const int r = R0 + i;
@@ -1256,31 +1259,45 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
     // instead of 12 for them) are the cheaper way through; one round: three rows per wave is the shorter critical path
     const bool two = module != 2 && (env_k == 2 || (env_k == 0 && items > slots_now));
     {
-      // the relay kernel (four waves per six rows of a strip): add 482^2 7.3 -> 5.25 us per iteration, 700^2 10.0 -> 8.4,
-      // 1000^2 10.4 -> 9.6; drain 482^2 12.0 -> 8.3, 1000^2 16.6 -> 12.9, 1600^2 34.7 -> 29.8 (profiles/r03/relay_sweep.txt)
+      // the relay kernel (four or eight waves per strip of six / eighteen rows): add 482^2 7.3 -> 5.2 us per iteration, 700^2
+      // 10.0 -> 7.3, 1200^2 14.8 -> 11.8, 1600^2 24.9 -> 23.2; drain 482^2 12.1 -> 8.2, 1000^2 16.3 -> 13.1, 1600^2 34.3 -> 25.5,
+      // 2400^2 51.6 -> 45.3, 3000^2 77.5 -> 67.3 (profiles/r03/relay_nw_sweep.txt)
       static std::atomic<int> env_relay{-1};
       if (env_relay < 0) { const char *t = getenv("WDPM_RELAY"); env_relay = t ? atoi(t) : 1; }
-      const int nch6 = (out_last - A0 - 1 + 5) / 6 > 0 ? (out_last - A0 - 1 + 5) / 6 : 1;
-      const long long nwg = (long long)nstr * nch6;
-      static std::atomic<int> simds{0};
-      if (!simds) {
+      static std::atomic<int> env_nw{-1};     // WDPM_RELAY_NW=4|8 forces the workgroup's height (tuning); 0 = automatic
+      if (env_nw < 0) { const char *t = getenv("WDPM_RELAY_NW"); env_nw = t ? atoi(t) : 0; }
+      static std::atomic<int> ncus{0};
+      if (!ncus) {
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        simds = 4 * cus;
+        ncus = cus;
       }
-      // Up to one wave per SIMD: always.  Beyond that, up to 6.5 waves per SIMD for add / subtract and 18 for drain (where the
-      // sweeps break even: add 1200^2 14.2 against 14.9 us, 1600^2 behind; drain 2000^2 40.6 against 44.1, 2400^2 behind) - where
-      // the triangle kernel would run in one round anyway, or the raster is known to be mostly wet: like the triangle kernel this
-      // one keeps no dry-tile flags (see `wide` above)
-      const long long nsimd = simds.load(std::memory_order_relaxed), waves4 = nwg * 4;
-      const long long deep = module == 2 ? 18 * nsimd : 13 * nsimd / 2;
+      const long long cus = ncus.load(std::memory_order_relaxed);
+      const int rows_out = out_last - A0 - 1;
+      const long long nwg4 = (long long)nstr * ((rows_out + 5) / 6 > 0 ? (rows_out + 5) / 6 : 1);        // four waves: six rows out of twelve
+      const long long nwg8 = (long long)nstr * ((rows_out + 17) / 18 > 0 ? (rows_out + 17) / 18 : 1);    // eight waves: 18 out of 24
+      // rounds of workgroups at two waves per SIMD (a CU holds two workgroups of four waves or one of eight); the taller workgroup
+      // where it needs fewer rounds: fewer waves and less re-reading per row, but twice as many rows behind one barrier
+      const long long r4 = (nwg4 + 2 * cus - 1) / (2 * cus), r8 = (nwg8 + cus - 1) / cus;
+      const bool tall = env_nw == 8 || (env_nw == 0 && r8 < r4);
+      long long nwg = tall ? nwg8 : nwg4;
+      // With every wave on a SIMD of its own: always.  Beyond that, while the sweeps (profiles/r03/relay_nw_sweep.txt) have it ahead
+      // of the triangle / marching kernels - add / subtract up to five rounds (1600^2 23.2 against 24.9 us, 2000^2 a tie, 2400^2
+      // behind), drain up to fourteen (3000^2 67 against 78 us, 3600^2 behind) - and where the triangle kernel would run in one
+      // round anyway or the raster is known to be mostly wet: like the triangle kernel this one keeps no dry-tile flags (`wide`)
       const bool relay_ok = env_tri && !signed_zero_safe && chunk_rows < 3 &&
-                            (waves4 <= nsimd || ((wide || items <= slots_now) && waves4 <= deep) || env_relay == 2);
+                            (nwg4 * 4 <= 4 * cus || ((wide || items <= slots_now) && (tall ? r8 : r4) <= (module == 2 ? 14 : 5)) ||
+                             env_relay == 2);
       if (env_relay && !fold_md && relay_ok) {
-        const dim3 rgrid(((unsigned)nwg + 7) / 8 * 8), rblock(256);
+        const dim3 rgrid(((unsigned)nwg + 7) / 8 * 8), rblock(tall ? 512 : 256);
 #define WDPM_RELAY_LAUNCH(...) hipLaunchKernelGGL((relay_iteration_kernel<__VA_ARGS__>), rgrid, rblock, 0, s, w_in, w_out, dem, g, nstr, (int)nwg, A0, out_last, thres, totaldrain, module == 2 ? drain_owed : 0)
-        if (module == 2) { if (flush) WDPM_RELAY_LAUNCH(2, true, false); else if (plain) WDPM_RELAY_LAUNCH(2, false, true); else WDPM_RELAY_LAUNCH(2, false, false); }
-        else if (flush) WDPM_RELAY_LAUNCH(0, true, false); else if (plain) WDPM_RELAY_LAUNCH(0, false, true); else WDPM_RELAY_LAUNCH(0, false, false);
+#define WDPM_RELAY_PICK(NW)                                                                                        \
+        do {                                                                                                       \
+          if (module == 2) { if (flush) WDPM_RELAY_LAUNCH(2, true, false, NW); else if (plain) WDPM_RELAY_LAUNCH(2, false, true, NW); else WDPM_RELAY_LAUNCH(2, false, false, NW); } \
+          else if (flush) WDPM_RELAY_LAUNCH(0, true, false, NW); else if (plain) WDPM_RELAY_LAUNCH(0, false, true, NW); else WDPM_RELAY_LAUNCH(0, false, false, NW); \
+        } while (0)
+        if (tall) WDPM_RELAY_PICK(8); else WDPM_RELAY_PICK(4);
+#undef WDPM_RELAY_PICK
 #undef WDPM_RELAY_LAUNCH
         return hipGetLastError();
       }
