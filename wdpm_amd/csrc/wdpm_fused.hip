@@ -39,6 +39,14 @@
  *
  * Results are bit-identical to the serial reference: same operands, same order, fp64, no FMA in
  * the stencil (the DEM decode uses two, on values it has been verified to reproduce exactly).
+ *
+ * Three kernels share the per-block arithmetic (block_update / blocks_lockstep) and the trapezoid:
+ *   fused_iteration_kernel  the marching window above: rasters that fill the chip (from ~2000^2 add, ~3600^2 drain)
+ *   relay_iteration_kernel  workgroups of four / eight waves, one row block per wave and row alignment, shared rows passed
+ *                           through LDS: small and mid-size rasters (round 3; 482^2 add 7.3 -> 5.2 us, drain 12.1 -> 8.4)
+ *   tri_iteration_kernel    one wave, nine (twelve) rows in, three (six) out, row blocks in lockstep: what is between the two,
+ *                           and a small raster's last launch of a block (max diff folded in)
+ * wdpm_launch_fused_rows picks by size, module and what is known about the raster (DESIGN.md §4.1c, §4.1c').
  */
 #include "wdpm_kernels.h"
 #include "wdpm_stencil.h"
