@@ -9,3 +9,8 @@ echo "== the same call sequences and row-block jobs with six rows per triangle w
 for t in "tests/test_hip_parity.py -k random_call" "tests/test_rowblock.py -k hip_random_group" "tests/test_hip_parity.py -k every_"; do
   WDPM_TRI_K=2 WDPM_FUZZ_SEEDS=$lo:$hi timeout -k 10 900 python -m pytest $t -m gpu -q -x 2>&1 | tail -n 3
 done
+echo "== the same with the relay kernel's workgroups at eight waves forced everywhere (WDPM_RELAY=2 WDPM_RELAY_NW=8), and with the relay kernel off"
+for t in "tests/test_hip_parity.py -k random_call" "tests/test_rowblock.py -k hip_random_group" "tests/test_hip_parity.py -k every_"; do
+  WDPM_RELAY=2 WDPM_RELAY_NW=8 WDPM_FUZZ_SEEDS=$lo:$hi timeout -k 10 900 python -m pytest $t -m gpu -q -x 2>&1 | tail -n 3
+  WDPM_RELAY=0 WDPM_FUZZ_SEEDS=$lo:$hi timeout -k 10 900 python -m pytest $t -m gpu -q -x 2>&1 | tail -n 3
+done
