@@ -993,11 +993,12 @@ tri_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout, 
 // Nine block stages for six rows, as in the six-row triangle wave, but three in a row per wave instead of nine.  Same trapezoid,
 // same pass order per cell, same arithmetic (stage_lockstep with one block): bit-identical.
 // ---------------------------------------------------------------------------------------------
-template <int MODULE, bool FLUSH, bool PLAIN, int NW = 4>
+template <int MODULE, bool FLUSH, bool PLAIN, int NW = 4, bool DEM32 = false>
 __global__ void __launch_bounds__(64 * NW, 2)
 relay_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout, const double *__restrict__ dem,
                        const SlabGeom g, const int nstrips, const int nwg, const int A0, const int out_last, const double thres,
-                       double *__restrict__ totaldrain, const int drain_owed) {
+                       double *__restrict__ totaldrain, const int drain_owed, const DemCode code) {
+  static_assert(!DEM32 || (MODULE != 2 && NW == 8), "the DEM as 32-bit codes: add / subtract launches of several rounds");
   const int lane = threadIdx.x & 63;
   const int vb = (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8;       // XCD-contiguous workgroups
   if (vb >= nwg) return;                                                    // workgroup-uniform: nobody is left at a barrier
@@ -1021,19 +1022,31 @@ relay_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
 #pragma unroll
   for (int j = 0; j < 3; j++) voff[j] = 8u * (unsigned)(colb + j < g.ncp ? colb + j : g.ncp - 1);
   double W[7][3], D[7][3];                        // slots 0 .. 4 are used (seven: stage_impl's window type)
+  // Every wave fetches its own three rows of water and of elevations.  The elevations of the two rows it takes over later are
+  // static data the wave below holds anyway: they come with the water through LDS (LDSDEM) where the launch is more than a
+  // round of waves - five rows of DEM fetched per wave made those memory-bound (add 2000^2 32.9 -> 30.0 us, 3000^2 66.7 -> 63.0,
+  // drain 1200^2 15.0 -> 14.3) - and for drain; add / subtract workgroups of four waves, the one-round sizes, fetch all five
+  // themselves: there the extra LDS traffic sits on the latency path (482^2 5.23 against 5.38 us; profiles/r03/relay_ldsdem_ab.txt)
+  constexpr bool LDSDEM = NW == 8 || MODULE == 2;
 #pragma unroll
-  for (int i = 0; i < 5; i++) {
+  for (int i = 0; i < (LDSDEM ? 3 : 5); i++) {
     const int rc = R0 + i < g.rows ? R0 + i : g.rows - 1;
     const char *bw = reinterpret_cast<const char *>(win + (size_t)rc * pitch);
     const char *bd = reinterpret_cast<const char *>(dem + (size_t)rc * pitch);
+    const char *bq = reinterpret_cast<const char *>(code.q + (size_t)rc * pitch);
 #pragma unroll
     for (int j = 0; j < 3; j++) {
-      D[i][j] = *reinterpret_cast<const double *>(bd + voff[j]);
+      // DEM32: the elevations as verified-lossless 32-bit codes (wdpm_kernels.h::DemCode): launches of several rounds are bound
+      // by the memory system, and four bytes per cell less are worth nine decodes per wave there
+      if (DEM32) D[i][j] = dem32_decode(*reinterpret_cast<const int *>(bq + voff[j] / 2), code.k0, code.D, code.rD);
+      else D[i][j] = *reinterpret_cast<const double *>(bd + voff[j]);
       W[i][j] = i < 3 ? *reinterpret_cast<const double *>(bw + voff[j]) : 0.0;
     }
   }
 #pragma unroll
-  for (int j = 0; j < 3; j++) { W[5][j] = W[6][j] = 0.0; D[5][j] = D[6][j] = WDPM_INF; }
+  for (int i = (LDSDEM ? 3 : 5); i < 7; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) { W[i][j] = 0.0; D[i][j] = WDPM_INF; }
 
   // Drain: totaldrain is carried from row alignment to row alignment by whichever wave holds the outlet's block (at most one
   // per alignment and workgroup: wave-uniform arithmetic every wave can do), through LDS; the workgroup whose stored block
@@ -1081,7 +1094,7 @@ relay_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
     }
   }
 #pragma unroll
-  for (int i = 0; i < 5; i++)
+  for (int i = 0; i < (LDSDEM ? 3 : 5); i++)
 #pragma unroll
     for (int j = 0; j < 3; j++) {
       if (FLUSH && i < 3) W[i][j] = W[i][j] < thres ? 0.0 : W[i][j];               // WDPMCL.c:1059-1062
@@ -1090,6 +1103,7 @@ relay_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
       D[i][j] = ok ? D[i][j] : WDPM_INF;
     }
   __shared__ double xch[2][NW][3 * kLanes];
+  __shared__ double xdem[LDSDEM ? 2 : 1][LDSDEM ? NW : 1][LDSDEM ? 3 * kLanes : 1];   // elevations of a wave's first two rows, for the wave above
   __shared__ double td_sh[3];
   // one row alignment on this wave's block at slots S0 .. S0+2 (st = S0): the outlet's block takes block_update's outlet form
 #define WDPM_RELAY_STAGE(S0)                                                                               \
@@ -1103,12 +1117,24 @@ relay_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
   } while (0)
   WDPM_RELAY_STAGE(0);                                                        // oi = 1
 #pragma unroll
-  for (int j = 0; j < 3; j++) xch[0][wave][j * kLanes + lane] = W[0][j];
+  for (int j = 0; j < 3; j++) {
+    xch[0][wave][j * kLanes + lane] = W[0][j];
+    if (LDSDEM) {
+      xdem[0][wave][j * kLanes + lane] = D[0][j];
+      xdem[1][wave][j * kLanes + lane] = D[1][j];
+    }
+  }
   __syncthreads();
   if (MODULE == 2 && wo[0] >= 0) ds.td = td_sh[0];
   if (wave < NW - 1) {
 #pragma unroll
-    for (int j = 0; j < 3; j++) W[3][j] = xch[0][wave + 1][j * kLanes + lane];
+    for (int j = 0; j < 3; j++) {
+      W[3][j] = xch[0][wave + 1][j * kLanes + lane];
+      if (LDSDEM) {
+        D[3][j] = xdem[0][wave + 1][j * kLanes + lane];
+        D[4][j] = xdem[1][wave + 1][j * kLanes + lane];
+      }
+    }
     WDPM_RELAY_STAGE(1);                                                      // oi = 2
   }
 #pragma unroll
@@ -1290,21 +1316,27 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
       const bool tall = env_nw == 8 || (env_nw == 0 && r8 < r4);
       long long nwg = tall ? nwg8 : nwg4;
       // With every wave on a SIMD of its own: always.  Beyond that, while the sweeps (profiles/r03/relay_nw_sweep.txt) have it ahead
-      // of the triangle / marching kernels - add / subtract up to five rounds (1600^2 23.2 against 24.9 us, 2000^2 a tie, 2400^2
-      // behind), drain up to fourteen (3000^2 67 against 78 us, 3600^2 behind) - and where the triangle kernel would run in one
+      // of the triangle / marching kernels - add / subtract up to eight rounds (1600^2 20.2 against 24.8 us, 2000^2 28.6 against 33.9,
+      // 2400^2 39.0 against 42.4, 3000^2 a tie), drain up to fourteen (3000^2 67 against 78 us, 3600^2 behind) - and where the triangle kernel would run in one
       // round anyway or the raster is known to be mostly wet: like the triangle kernel this one keeps no dry-tile flags (`wide`)
       const bool relay_ok = env_tri && !signed_zero_safe && chunk_rows < 3 &&
-                            (nwg4 * 4 <= 4 * cus || ((wide || items <= slots_now) && (tall ? r8 : r4) <= (module == 2 ? 14 : 5)) ||
+                            (nwg4 * 4 <= 4 * cus || ((wide || items <= slots_now) && (tall ? r8 : r4) <= (module == 2 ? 14 : 8)) ||
                              env_relay == 2);
       if (env_relay && !fold_md && relay_ok) {
         const dim3 rgrid(((unsigned)nwg + 7) / 8 * 8), rblock(tall ? 512 : 256);
-#define WDPM_RELAY_LAUNCH(...) hipLaunchKernelGGL((relay_iteration_kernel<__VA_ARGS__>), rgrid, rblock, 0, s, w_in, w_out, dem, g, nstr, (int)nwg, A0, out_last, thres, totaldrain, module == 2 ? drain_owed : 0)
+#define WDPM_RELAY_LAUNCH(...) hipLaunchKernelGGL((relay_iteration_kernel<__VA_ARGS__>), rgrid, rblock, 0, s, w_in, w_out, dem, g, nstr, (int)nwg, A0, out_last, thres, totaldrain, module == 2 ? drain_owed : 0, code)
 #define WDPM_RELAY_PICK(NW)                                                                                        \
         do {                                                                                                       \
           if (module == 2) { if (flush) WDPM_RELAY_LAUNCH(2, true, false, NW); else if (plain) WDPM_RELAY_LAUNCH(2, false, true, NW); else WDPM_RELAY_LAUNCH(2, false, false, NW); } \
           else if (flush) WDPM_RELAY_LAUNCH(0, true, false, NW); else if (plain) WDPM_RELAY_LAUNCH(0, false, true, NW); else WDPM_RELAY_LAUNCH(0, false, false, NW); \
         } while (0)
-        if (tall) WDPM_RELAY_PICK(8); else WDPM_RELAY_PICK(4);
+        static std::atomic<int> env_r32{-1};     // WDPM_RELAY_DEM32=0: the fp64 DEM in the relay kernel (A/B)
+        if (env_r32 < 0) { const char *t = getenv("WDPM_RELAY_DEM32"); env_r32 = t ? atoi(t) : 1; }
+        // from two rounds of workgroups on (700^2, one round: 7.05 against 7.5 us with the decode on the latency path; 1200^2 11.7 ->
+        // 10.95, 1600^2 22.0 -> 20.2, 2400^2 42.9 -> 39.0; profiles/r03/relay_dem32_ab.txt)
+        if (tall && module != 2 && code.q != nullptr && env_r32 && (r8 >= 2 || code.force)) {
+          if (flush) WDPM_RELAY_LAUNCH(0, true, false, 8, true); else if (plain) WDPM_RELAY_LAUNCH(0, false, true, 8, true); else WDPM_RELAY_LAUNCH(0, false, false, 8, true);
+        } else if (tall) WDPM_RELAY_PICK(8); else WDPM_RELAY_PICK(4);
 #undef WDPM_RELAY_PICK
 #undef WDPM_RELAY_LAUNCH
         return hipGetLastError();
