@@ -53,6 +53,7 @@
 
 #include <atomic>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 namespace {
@@ -310,7 +311,7 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
                        const double *__restrict__ dem, const DemCode code, const SlabGeom g, const int nstrips,
                        const int nitems, const int H, const int A0, const int out_last,
                        double *__restrict__ totaldrain, const double thres, const int drain_owed,
-                       const TileFlags tf, const MaxDiffArgs md) {
+                       const TileFlags tf, const MaxDiffArgs md, const int store_plain) {
   const int lane = threadIdx.x & 63;
   // Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2; placement is only a
   // speed matter, never correctness): give each XCD a contiguous run of work items so that the
@@ -521,8 +522,16 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
         const bool row_ok = r >= or_lo && r <= or_hi;             // wave-uniform
         // rows outside the chunk's output range (first / last trips only) go to the dump area
         double *const orow = wout + (size_t)(row_ok ? r : 0) * pitch + c0;
+        // store_plain (wave-uniform; round 3): ordinary stores where the raster the next iteration reads back fits the Infinity
+        // Cache in good part - add 3600^2 79.8 -> 76.2 us, 4096^2 96.3 -> 91.6, 6000^2 192.9 -> 181.0, 8192^2 -2 %, 16384^2 -0.9 %;
+        // below that and for drain non-temporal stores are ahead (2400^2 42.8 against 43.6; profiles/r03/plain_stores_ab.txt)
+        if (store_plain) {
 #pragma unroll
-        for (int k = 0; k < 3; k++) __builtin_nontemporal_store(staged[i][k], row_ok ? orow + scol[k] : dump);
+          for (int k = 0; k < 3; k++) *(row_ok ? orow + scol[k] : dump) = staged[i][k];
+        } else {
+#pragma unroll
+          for (int k = 0; k < 3; k++) __builtin_nontemporal_store(staged[i][k], row_ok ? orow + scol[k] : dump);
+        }
       }
       __builtin_amdgcn_wave_barrier();
     };
@@ -997,7 +1006,7 @@ template <int MODULE, bool FLUSH, bool PLAIN, int NW = 4, bool DEM32 = false>
 __global__ void __launch_bounds__(64 * NW, 2)
 relay_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout, const double *__restrict__ dem,
                        const SlabGeom g, const int nstrips, const int nwg, const int A0, const int out_last, const double thres,
-                       double *__restrict__ totaldrain, const int drain_owed, const DemCode code) {
+                       double *__restrict__ totaldrain, const int drain_owed, const DemCode code, const int store_plain) {
   static_assert(!DEM32 || (MODULE != 2 && NW == 8), "the DEM as 32-bit codes: add / subtract launches of several rounds");
   const int lane = threadIdx.x & 63;
   const int vb = (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8;       // XCD-contiguous workgroups
@@ -1103,7 +1112,7 @@ relay_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
       D[i][j] = ok ? D[i][j] : WDPM_INF;
     }
   __shared__ double xch[2][NW][3 * kLanes];
-  __shared__ double xdem[LDSDEM ? 2 : 1][LDSDEM ? NW : 1][LDSDEM ? 3 * kLanes : 1];   // elevations of a wave's first two rows, for the wave above
+  __shared__ double xdem[2][LDSDEM ? NW : 1][LDSDEM ? 3 * kLanes : 1];   // elevations of a wave's first two rows, for the wave above
   __shared__ double td_sh[3];
   // one row alignment on this wave's block at slots S0 .. S0+2 (st = S0): the outlet's block takes block_update's outlet form
 #define WDPM_RELAY_STAGE(S0)                                                                               \
@@ -1147,8 +1156,34 @@ relay_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
   WDPM_RELAY_STAGE(2);                                                        // oi = 3
 #undef WDPM_RELAY_STAGE
   // wave w stores rows A+3w+2 .. A+3w+4 (wave 0 also rows 0, 1 of the raster's first chunk)
+  if (LDSDEM) {
+    // Through the wave's LDS slices (free since the second barrier), so that one store instruction writes 512 contiguous
+    // bytes - as the marching kernel does.  Lane by lane a wave's three stores per row interleave at 24-byte strides, and as
+    // non-temporal stores they reach the memory as partial lines: 52 MB written per 2000^2 launch for 32 MB of raster
+    // (profiles/r03/add2000_pmc_summary.json; add 2000^2 28.9 -> 26.1 us, 3000^2 58.2 -> 50.8, relay_stores_ab.txt).  Lanes past
+    // the exact output range are clamped onto its last column.  store_plain: see fused_iteration_kernel.
+    double *const t[3] = {&xdem[0][wave][0], &xdem[1][wave][0], &xch[0][wave][0]};
 #pragma unroll
-  for (int i = 0; i < 5; i++) {
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) t[i][3 * lane + j] = W[2 + i][j];
+    __builtin_amdgcn_wave_barrier();
+    const int lo = oc_lo - c0, hi = oc_hi - c0;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const int r = R0 + 2 + i;
+      if (r < or_lo || r > or_hi) continue;                                         // wave-uniform
+#pragma unroll
+      for (int kk = 0; kk < 3; kk++) {
+        const int c = lo + 64 * kk + lane < hi ? lo + 64 * kk + lane : hi;
+        double *const q = wout + (size_t)r * pitch + c0 + c;
+        if (store_plain) *q = t[i][c];
+        else __builtin_nontemporal_store(t[i][c], q);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < (LDSDEM ? 2 : 5); i++) {
     const int r = R0 + i;
     if (r < or_lo || r > or_hi || (i < 2 && !(wave == 0 && A == 0))) continue;    // wave-uniform
 #pragma unroll
@@ -1183,6 +1218,13 @@ static int resident_waves() {
     blocks = 2;
   cached.store(cus * blocks * 4, std::memory_order_relaxed);
   return cus * blocks * 4;
+}
+
+/* WDPM_STORES=nt|plain forces the water raster's store policy (A/B); default 0 = by size and module */
+static int env_stores() {
+  static std::atomic<int> v{-1};
+  if (v < 0) { const char *e = getenv("WDPM_STORES"); v = !e ? 0 : (!strcmp(e, "plain") ? 2 : (!strcmp(e, "nt") ? 1 : 0)); }
+  return v;
 }
 
 /* chunk height in rows (multiple of 3): the rows are cut into as many chunks as keep
@@ -1324,7 +1366,8 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
                              env_relay == 2);
       if (env_relay && !fold_md && relay_ok) {
         const dim3 rgrid(((unsigned)nwg + 7) / 8 * 8), rblock(tall ? 512 : 256);
-#define WDPM_RELAY_LAUNCH(...) hipLaunchKernelGGL((relay_iteration_kernel<__VA_ARGS__>), rgrid, rblock, 0, s, w_in, w_out, dem, g, nstr, (int)nwg, A0, out_last, thres, totaldrain, module == 2 ? drain_owed : 0, code)
+        const int relay_plain = env_stores() == 2 || (env_stores() == 0 && module != 2 && tall && r8 >= 6);   // 2000^2 25.8 -> 25.1 us, 3000^2 50.1 -> 46.1
+#define WDPM_RELAY_LAUNCH(...) hipLaunchKernelGGL((relay_iteration_kernel<__VA_ARGS__>), rgrid, rblock, 0, s, w_in, w_out, dem, g, nstr, (int)nwg, A0, out_last, thres, totaldrain, module == 2 ? drain_owed : 0, code, relay_plain)
 #define WDPM_RELAY_PICK(NW)                                                                                        \
         do {                                                                                                       \
           if (module == 2) { if (flush) WDPM_RELAY_LAUNCH(2, true, false, NW); else if (plain) WDPM_RELAY_LAUNCH(2, false, true, NW); else WDPM_RELAY_LAUNCH(2, false, false, NW); } \
@@ -1429,7 +1472,8 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
   const MaxDiffArgs mda = fold_md ? *md : MaxDiffArgs{nullptr, 0.0, 0, 0, nullptr};
   if (fold_md) tf = TileFlags{nullptr, nullptr, 0, nullptr, nchunks};   /* every wave must look at its block: no skipping in this launch */
   if (fold_md && tiles) tiles->maintained = 0;
-#define WDPM_LAUNCH(...) hipLaunchKernelGGL((fused_iteration_kernel<__VA_ARGS__>), grid, block, 0, s, w_in, w_out, dem, code, g, nstrips, nitems, H, A0, out_last, totaldrain, thres, module == 2 ? drain_owed : 0, tf, mda)
+  const int store_plain = env_stores() == 2 || (env_stores() == 0 && module != 2 && (long long)(out_last - A0 + 1) * g.ncp >= 11000000LL);
+#define WDPM_LAUNCH(...) hipLaunchKernelGGL((fused_iteration_kernel<__VA_ARGS__>), grid, block, 0, s, w_in, w_out, dem, code, g, nstrips, nitems, H, A0, out_last, totaldrain, thres, module == 2 ? drain_owed : 0, tf, mda, store_plain)
 #define WDPM_LAUNCH_FM(M, Z, D32) do { if (fold_md) { if (flush) WDPM_LAUNCH(M, Z, D32, true, true); else WDPM_LAUNCH(M, Z, D32, false, true); } \
                                        else { if (flush) WDPM_LAUNCH(M, Z, D32, true, false); else WDPM_LAUNCH(M, Z, D32, false, false); } } while (0)
   if (module == 2 && fast && plain) WDPM_LAUNCH(2, false, false, false, false, true);
