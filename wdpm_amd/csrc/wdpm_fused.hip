@@ -294,6 +294,9 @@ __device__ __forceinline__ void three_stages(double (&W)[7][3], const double (&D
 #ifndef WDPM_FUSED_MIN_WAVES
 #define WDPM_FUSED_MIN_WAVES 2   /* waves per SIMD the register allocator must leave room for */
 #endif
+#ifndef WDPM_FUSED_CODES_WAVES
+#define WDPM_FUSED_CODES_WAVES 2 /* the same for the add / subtract instances that stream the DEM as codes */
+#endif
 
 /* raw registers of the row prefetch.  DEM32: the dem rows arrive as 32-bit codes — interior waves
  * fetch a lane's three columns with one 12-byte load (qi), edge waves column by column (qe).
@@ -306,7 +309,7 @@ struct Prefetched {
 };
 
 template <int MODULE, bool SZ_SAFE, bool DEM32, bool FLUSH = false, bool MD = false, bool PLAIN = false>
-__global__ void __launch_bounds__(256, WDPM_FUSED_MIN_WAVES)
+__global__ void __launch_bounds__(256, (MODULE != 2 && DEM32 && !MD && !SZ_SAFE) ? WDPM_FUSED_CODES_WAVES : WDPM_FUSED_MIN_WAVES)
 fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout,
                        const double *__restrict__ dem, const DemCode code, const SlabGeom g, const int nstrips,
                        const int nitems, const int H, const int A0, const int out_last,
@@ -1412,7 +1415,7 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
   // ... and only pays on launches big enough for two waves per SIMD (see below): at one wave per SIMD
   // the wave's own latency chain is the limit and the nine decodes per step cost 3-5 % (size sweep in
   // profiles/r01: 512^2 - 3072^2 slower with codes, 4096^2 and up 5-12 % faster).
-  const bool big = (long long)(out_last - A0 + 1) * nstrips >= 36LL * resident_waves<0, false, true>();
+  const bool big = (long long)(out_last - A0 + 1) * nstrips >= 36LL * resident_waves<0, false>();
   const bool dem32 = fast && module != 2 && code.q != nullptr && (big || code.force);
   int slots = module == 2 ? (fast ? resident_waves<2, false>() : resident_waves<2, true>())
               : dem32     ? resident_waves<0, false, true>()
