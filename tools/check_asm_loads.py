@@ -113,11 +113,34 @@ def check(name, body):
     return [reports[k] for k in sorted(reports)]
 
 
+def check_exec_dpp(body):
+    """gfx9 hazard the compiler cannot see inside inline asm: a VALU instruction that writes EXEC (v_cmpx in
+    wdpm_stencil.h::select_gt_exec) must be 5 wait states away from the next DPP instruction.  Counted along the
+    listing (every instruction one wait state, s_nop N: N + 1) - branches are not followed: the window is 5 instructions."""
+    out, since = [], None
+    for ln, t, in_asm in body:
+        if t.endswith(":"):
+            continue
+        if "v_cmpx" in t:
+            since = 0
+            continue
+        if since is None:
+            continue
+        if re.search(r"\b(row_shl|row_shr|row_ror|wave_shl|wave_shr|wave_rol|wave_ror|row_mirror|row_half_mirror|row_bcast|quad_perm|row_newbcast)", t):
+            if since < 5:
+                out.append(f"line {ln}: DPP `{t}` only {since} wait states after a v_cmpx")
+        m = re.match(r"s_nop (\d+)", t)
+        since += int(m.group(1)) + 1 if m else 1
+        if since >= 5:
+            since = None
+    return out
+
+
 def main():
     lines = open(sys.argv[1]).read().splitlines()
     bad = 0
     for name, body in kernels(lines):
-        for r in check(name, body):
+        for r in check(name, body) + check_exec_dpp(body):
             print(f"{name[:60]}: {r}")
             bad += 1
     print("asm prefetch check:", "OK" if not bad else f"{bad} violations")

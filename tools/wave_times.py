@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""When do the waves of one marching-kernel launch start and end?  Needs a timing build of the library
+(make EXTRA=-DWDPM_WAVE_TIMES, pointed at with WDPM_HIP_LIB): every wave leaves its start / end time
+(s_memrealtime, 100 MHz), its XCD and its strip / chunk in a device array, read back here after a steady
+launch.      wave_times.py [size=16384] [rows=size] [module=add]
+Prints the launch's span, how the ends spread (the tail is what a one-round launch pays for imbalance),
+and the same per XCD."""
+import ctypes, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import wdpm_amd
+C = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+R = int(sys.argv[2]) if len(sys.argv) > 2 else C
+module = sys.argv[3] if len(sys.argv) > 3 else "add"
+lib = wdpm_amd.load_hip()
+raw = ctypes.CDLL(os.environ["WDPM_HIP_LIB"])
+rng = np.random.default_rng(1)
+bd = np.full((R + 2, C + 2), -99999.0); bd[1:-1, 1:-1] = np.round(500 + rng.random((R, C)), 4)
+bw = np.where(bd > -99999.0, 0.1, 0.0)
+kw = {}
+if module == "drain":
+    k = int(np.argmin(np.where(bd > 0, bd, np.inf))); kw = dict(drainrow=k // (C + 2), draincol=k % (C + 2))
+with lib.context(module=module, nrows=R, ncols=C, missingvalue=-99999.0, kernel=wdpm_amd.KERNEL_FUSED, **kw) as c:
+    c.upload(bd, bw); c.iterate(30); c.synchronize()
+    for rep in range(3):
+        c.iterate(5); c.synchronize()
+        buf = np.zeros((8192, 4), dtype=np.uint64)
+        rc = raw.wdpm_debug_wave_times(buf.ctypes.data_as(ctypes.c_void_p), 8192)
+        assert rc == 0
+        t = buf[buf[:, 1] > 0]
+        n = len(t)
+        t0 = t[:, 0].astype(np.int64); t1 = t[:, 1].astype(np.int64)
+        base = t0.min(); s = (t0 - base) / 100.0; e = (t1 - base) / 100.0   # us
+        span = e.max()
+        xcc = (t[:, 2] >> np.uint64(32)).astype(int) & 15
+        strip = (t[:, 3] >> np.uint64(32)).astype(int); chunk = (t[:, 3] & np.uint64(0xffffffff)).astype(int)
+        dur = e - s
+        print(f"== {R}x{C} {module}, launch {rep}: {n} waves ({strip.max()+1} strips x {chunk.max()+1} chunks), span {span:.1f} us")
+        print("   starts  p50 %.1f  p90 %.1f  p99 %.1f  max %.1f us" % tuple(np.percentile(s, [50, 90, 99, 100])))
+        print("   ends    p1 %.1f  p10 %.1f  p50 %.1f  p90 %.1f  p99 %.1f  max %.1f us" % tuple(np.percentile(e, [1, 10, 50, 90, 99, 100])))
+        print("   durations  min %.1f  p50 %.1f  p90 %.1f  max %.1f us;  wave-time in flight / (waves x span) = %.3f" %
+              (dur.min(), np.median(dur), np.percentile(dur, 90), dur.max(), dur.sum() / (n * span)))
+        slot = (t[:, 2] & np.uint64(15)).astype(int); simd = ((t[:, 2] >> np.uint64(4)) & np.uint64(3)).astype(int)
+        print("   wave slots used:", {int(k): int((slot == k).sum()) for k in np.unique(slot)},
+              " median end by slot:", {int(k): round(float(np.median(e[slot == k])), 1) for k in np.unique(slot)})
+        for x in range(8):
+            m = xcc == x
+            if m.any():
+                print("   XCD %d: %4d waves, median duration %.1f, last end %.1f us" % (x, m.sum(), np.median(dur[m]), e[m].max()))
+        last = np.argsort(e)[-8:]
+        print("   last to end (strip, chunk, xcd, start, end):", [(int(strip[i]), int(chunk[i]), int(xcc[i]), round(float(s[i]), 1), round(float(e[i]), 1)) for i in last])
+        first = np.argsort(e)[:4]
+        print("   first to end:", [(int(strip[i]), int(chunk[i]), int(xcc[i]), round(float(s[i]), 1), round(float(e[i]), 1)) for i in first])

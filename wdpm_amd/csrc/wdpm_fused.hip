@@ -10,9 +10,10 @@
  *    only a wave-private transpose buffer for the stores).  Lane m owns raster columns
  *    c0+3m .. c0+3m+2, so a wave covers a 192-column strip and a 64-lane row load is one
  *    contiguous 1536-byte segment.  Waves per SIMD: one for add/subtract on the fp64 DEM, two for drain
- *    (bound by instruction issue) and for add/subtract on the DEM codes below.  Neither resource is idle in
- *    the add kernel: fp64 VALU issue is ~85 % busy (SQ_INSTS_VALU x 4 / SIMD over GRBM_GUI_ACTIVE / 8) while
- *    the memory system carries 4.4-4.7 TB/s, what a plain 2-read : 1-write triad reaches on this chip
+ *    (bound by instruction issue) and for add/subtract on the DEM codes below.  The two waves of a SIMD are kept
+ *    in step by issue priorities that fall as a wave advances (PRIO instantiations, tall chunks: see the marching
+ *    loop); with that the add kernel issues fp64 VALU instructions in ~95 % of its cycles (SQ_INSTS_VALU x 4 / SIMD
+ *    over GRBM_GUI_ACTIVE / 8; 85 % before) while the memory system carries ~4.8 TB/s
  *    ("what the add kernel is bound by").
  *  - The wave marches down a chunk of rows with a 7-row window held in registers (dem + water,
  *    3 columns per lane).  Each step loads 3 new rows and applies, in this order, row alignment
@@ -121,35 +122,37 @@ __device__ __forceinline__ void step_drain(const double dc, double &wc, const do
  * max(ht / 8, -0.0) = +-0; NODATA centre (dem = +inf): inf > en gives x = w_c = 0, and next to a NODATA neighbour ht is NaN,
  * which v_max turns into -0.0 - and w + (+-0) == w, w - |+-0| == w for every w that is not -0.0.  (drain: the same through
  * min(max(x / 8, -0.0), w_c = 0).)  Four instructions per block less for add, eight for drain. */
-template <int MODULE, bool SZ_SAFE, bool OUTLET = true, bool PLAIN = false>
+/* FLAGS: bit 0 = PLAIN, bit 1 = XSEL (wdpm_stencil.h::select_gt_exec) */
+template <int MODULE, bool SZ_SAFE, bool OUTLET = true, int FLAGS = 0>
 __device__ __forceinline__ void block_update(
     double &w00, double &w01, double &w02, double &w10, double &w11, double &w12, double &w20, double &w21,
     double &w22, const double d00, const double d01, const double d02, const double d10, const double d11,
     const double d12, const double d20, const double d21, const double d22,
     const bool rd0, const bool rd1, const bool rd2, const bool cd0, const bool cd1, const bool cd2,
     DrainState &ds) {
+  constexpr bool PLAIN = (FLAGS & 1) != 0, XS = (FLAGS & 2) != 0;
   double wc = w11;
   bool gate = (wc > 0.0) & (d11 < WDPM_INF);            // WDPMCL.c:1099
   if (MODULE == 2 && !OUTLET && !SZ_SAFE && PLAIN) {
-    flow_drain_nz(d11, wc, d00, w00);
-    flow_drain_nz(d11, wc, d01, w01);
-    flow_drain_nz(d11, wc, d02, w02);
-    flow_drain_nz(d11, wc, d10, w10);
-    flow_drain_nz(d11, wc, d12, w12);
-    flow_drain_nz(d11, wc, d20, w20);
-    flow_drain_nz(d11, wc, d21, w21);
-    flow_drain_nz(d11, wc, d22, w22);
+    flow_drain_nz<XS>(d11, wc, d00, w00);
+    flow_drain_nz<XS>(d11, wc, d01, w01);
+    flow_drain_nz<XS>(d11, wc, d02, w02);
+    flow_drain_nz<XS>(d11, wc, d10, w10);
+    flow_drain_nz<XS>(d11, wc, d12, w12);
+    flow_drain_nz<XS>(d11, wc, d20, w20);
+    flow_drain_nz<XS>(d11, wc, d21, w21);
+    flow_drain_nz<XS>(d11, wc, d22, w22);
   } else if (MODULE == 2 && !OUTLET && !SZ_SAFE) {
     const double dce = gate ? d11 : -WDPM_INF;           // see flow_drain_nz
     wc = gate ? wc : 0.0;                                // its clamp needs a centre depth >= +0
-    flow_drain_nz(dce, wc, d00, w00);
-    flow_drain_nz(dce, wc, d01, w01);
-    flow_drain_nz(dce, wc, d02, w02);
-    flow_drain_nz(dce, wc, d10, w10);
-    flow_drain_nz(dce, wc, d12, w12);
-    flow_drain_nz(dce, wc, d20, w20);
-    flow_drain_nz(dce, wc, d21, w21);
-    flow_drain_nz(dce, wc, d22, w22);
+    flow_drain_nz<XS>(dce, wc, d00, w00);
+    flow_drain_nz<XS>(dce, wc, d01, w01);
+    flow_drain_nz<XS>(dce, wc, d02, w02);
+    flow_drain_nz<XS>(dce, wc, d10, w10);
+    flow_drain_nz<XS>(dce, wc, d12, w12);
+    flow_drain_nz<XS>(dce, wc, d20, w20);
+    flow_drain_nz<XS>(dce, wc, d21, w21);
+    flow_drain_nz<XS>(dce, wc, d22, w22);
     wc = gate ? wc : w11;
   } else if (MODULE == 2 && !OUTLET) {
     flow_drain(d11, wc, d00, w00, gate);
@@ -182,7 +185,7 @@ __device__ __forceinline__ void block_update(
         wc = hit ? 0.0 : wc;                             // :1984
         hit_any = hit_any | hit;
       }
-      flow_drain_nz(dce, wc, dn, wn);                    // :1988-2000
+      flow_drain_nz<XS>(dce, wc, dn, wn);                    // :1988-2000
     };
     nb(d00, w00, rd0, any0, cd0);
     nb(d01, w01, rd0, any1, cd1);
@@ -213,14 +216,14 @@ __device__ __forceinline__ void block_update(
   } else if (!SZ_SAFE) {
     // no -0.0 in the raster: the gate rides on the centre elevation (see flow_add_nz) - or is not needed at all (PLAIN)
     const double dce = PLAIN ? d11 : (gate ? d11 : -WDPM_INF);
-    flow_add_nz(dce, wc, d00, w00);
-    flow_add_nz(dce, wc, d01, w01);
-    flow_add_nz(dce, wc, d02, w02);
-    flow_add_nz(dce, wc, d10, w10);
-    flow_add_nz(dce, wc, d12, w12);
-    flow_add_nz(dce, wc, d20, w20);
-    flow_add_nz(dce, wc, d21, w21);
-    flow_add_nz(dce, wc, d22, w22);
+    flow_add_nz<XS>(dce, wc, d00, w00);
+    flow_add_nz<XS>(dce, wc, d01, w01);
+    flow_add_nz<XS>(dce, wc, d02, w02);
+    flow_add_nz<XS>(dce, wc, d10, w10);
+    flow_add_nz<XS>(dce, wc, d12, w12);
+    flow_add_nz<XS>(dce, wc, d20, w20);
+    flow_add_nz<XS>(dce, wc, d21, w21);
+    flow_add_nz<XS>(dce, wc, d22, w22);
   } else {
     flow_add(d11, wc, d00, w00, gate);
     flow_add(d11, wc, d01, w01, gate);
@@ -235,7 +238,7 @@ __device__ __forceinline__ void block_update(
 }
 
 /* the three column alignments oj = 1,2,3 of one row alignment, on window slots S0..S0+2 */
-template <int MODULE, bool SZ_SAFE, int S0, bool OUTLET, bool PLAIN = false>
+template <int MODULE, bool SZ_SAFE, int S0, bool OUTLET, int PLAIN = 0>
 __device__ __forceinline__ void stage_impl(double (&W)[7][3], const double (&D)[7][3], const int row_s0,
                                            const int drain_row, const bool (&cdr)[5], DrainState &ds) {
   const bool rd0 = MODULE == 2 && OUTLET && row_s0 == drain_row;
@@ -277,7 +280,7 @@ __device__ __forceinline__ void stage_impl(double (&W)[7][3], const double (&D)[
  * those rows are never stored (a chunk stores from row A+2; for A = 0 the centre row is the raster's border or a slab's
  * first halo row, which is wrong from the first iteration after a refresh on anyway): dead work.  Leaving those three stage
  * executions out saves 3 of 3 (H/3 + 2): 9 % of a 27-row chunk, 5.6 % at 48 rows, 0.4 % at 780. */
-template <int MODULE, bool SZ_SAFE, int NSTAGES = 3, bool PLAIN = false>
+template <int MODULE, bool SZ_SAFE, int NSTAGES = 3, int PLAIN = 0>
 __device__ __forceinline__ void three_stages(double (&W)[7][3], const double (&D)[7][3], const int rbase,
                                              const int drain_row, const bool (&cdr)[5], DrainState &ds) {
   if (MODULE == 2 && drain_row >= rbase && drain_row <= rbase + 6) {           // wave-uniform, rare
@@ -291,8 +294,19 @@ __device__ __forceinline__ void three_stages(double (&W)[7][3], const double (&D
   }
 }
 
+#ifdef WDPM_WAVE_TIMES   /* timing builds only (tools/wave_times.py): when each wave of the marching kernel starts and ends, and where */
+__device__ unsigned long long g_wave_times[4 * 8192];
+#endif
 #ifndef WDPM_FUSED_MIN_WAVES
 #define WDPM_FUSED_MIN_WAVES 2   /* waves per SIMD the register allocator must leave room for */
+#endif
+#ifndef WDPM_XSEL
+#define WDPM_XSEL 0              /* 1: the PRIO instantiations' neighbour steps select through EXEC (wdpm_stencil.h::select_gt_exec):
+                                    measured slower with the s_nop its hazard needs (profiles/r03/xsel_ab.txt), off */
+#endif
+#ifndef WDPM_PRIO_OLD            /* PRIO instantiations: where a wave's issue priority drops a level, in 64ths of its chunk - see the marching loop */
+#define WDPM_PRIO_OLD 18, 45, 56
+#define WDPM_PRIO_YOUNG 37, 49, 62
 #endif
 #ifndef WDPM_FUSED_CODES_WAVES
 #define WDPM_FUSED_CODES_WAVES 2 /* the same for the add / subtract instances that stream the DEM as codes */
@@ -308,7 +322,7 @@ struct Prefetched {
   int qe[3][3];
 };
 
-template <int MODULE, bool SZ_SAFE, bool DEM32, bool FLUSH = false, bool MD = false, bool PLAIN = false>
+template <int MODULE, bool SZ_SAFE, bool DEM32, bool FLUSH = false, bool MD = false, bool PLAIN = false, bool PRIO = false>
 __global__ void __launch_bounds__(256, (MODULE != 2 && DEM32 && !MD && !SZ_SAFE) ? WDPM_FUSED_CODES_WAVES : WDPM_FUSED_MIN_WAVES)
 fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout,
                        const double *__restrict__ dem, const DemCode code, const SlabGeom g, const int nstrips,
@@ -326,6 +340,9 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int item = vb * 4 + wave;
   if (item >= nitems) return;                       // wave-uniform
+#ifdef WDPM_WAVE_TIMES
+  const unsigned long long wt0 = wall_clock64();
+#endif
   const int strip = item % nstrips, chunk = item / nstrips;
   const int c0 = kStripOut * strip;
   const int oc_lo = strip == 0 ? 0 : c0 + kHaloL;
@@ -581,7 +598,7 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
 
       const int rbase = A + 3 * n - 4;                 // slab row of window slot 0
 #ifndef WDPM_ABLATE_COMPUTE                            /* timing experiments only: memory pattern alone */
-      three_stages<MODULE, SZ_SAFE, NSTAGES, PLAIN>(W, D, rbase, g.dr, cdr, ds);
+      three_stages<MODULE, SZ_SAFE, NSTAGES, (PLAIN ? 1 : 0) | (PRIO && !SZ_SAFE && WDPM_XSEL ? 2 : 0)>(W, D, rbase, g.dr, cdr, ds);
 #else
 #pragma unroll
       for (int j = 0; j < 3; j++) W[0][j] += D[0][j] + D[1][j] + D[2][j];   // keep the dem loads alive
@@ -632,6 +649,36 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
         for (int j = 0; j < 3; j++) { W[k][j] = W[k + 3][j]; D[k][j] = D[k + 3][j]; }
     };
 
+    // The SIMD's arbiter serves the OLDER of its two waves first whenever both have an instruction ready.  Left alone, the older
+    // wave of every SIMD gets ~65 % of the issue slots, finishes its chunk at 0.65 of the launch's time, and the younger runs
+    // the last third alone with nobody to hide its latencies behind (tools/wave_times.py, profiles/r03/wave_times.txt: ends
+    // p50 761 us, p90 1149 us of a 1175 us launch; wave-time in flight / (waves x span) = 0.78).  So a wave's priority
+    // (s_setprio, four levels) FALLS as it advances, and the wave behind is served first; equal levels still go to the older
+    // wave (wave slot 0 when a launch starts on an empty chip), so its levels end earlier than the younger's (slot 1) -
+    // boundaries in 64ths of the chunk, from a two-wave model of the arbiter and a sweep on the chip: both waves of a
+    // SIMD now end within 1-2 % of each other (0.955 in flight), 16384^2 add 1.206 -> 1.165 ms, drain 8192^2 0.428 -> 0.412 ms
+    // (profiles/r03/prio_ab.txt).  Chunks of a few steps lose by it (add 4096^2, 18 steps: -4 %; the 1055-row drain slab, 11 steps:
+    // -5 %; add 6000^2, 38 steps: -1 %, 7000^2, 50 steps: +2 %; drain 6000^2, 38 steps: +3 %, 19 steps: 0 ... -1.5 %), and the
+    // loop's shape alone changes the compiler's schedule (166 instead of 238 VGPRs for the DEM-code instances, 1 % slower on short
+    // chunks): PRIO is an instantiation of its own, chosen by the host for launches of tall chunks (wdpm_launch_fused_rows).
+    // Priorities decide who issues, never what is computed.  WDPM_PRIO=0 in the environment: never.
+#define WDPM_MARCH_FROM(N0)                                                                                      \
+    if constexpr (PRIO) {                                                                                         \
+      constexpr int bo[3] = {WDPM_PRIO_OLD}, by[3] = {WDPM_PRIO_YOUNG};                                           \
+      const int slot_odd = __builtin_amdgcn_s_getreg((0 << 11) | 4) & 1;     /* HW_ID.WAVE_ID bit 0 */            \
+      const int b1 = slot_odd ? by[0] : bo[0], b2 = slot_odd ? by[1] : bo[1], b3 = slot_odd ? by[2] : bo[2];      \
+      _Pragma("nounroll") for (int q = 0; q < 4; q++) {                                                           \
+        int f_lo, f_hi;                                                                                           \
+        if (q == 0) { __builtin_amdgcn_s_setprio(3); f_lo = 0; f_hi = b1; }                                       \
+        else if (q == 1) { __builtin_amdgcn_s_setprio(2); f_lo = b1; f_hi = b2; }                                 \
+        else if (q == 2) { __builtin_amdgcn_s_setprio(1); f_lo = b2; f_hi = b3; }                                 \
+        else { __builtin_amdgcn_s_setprio(0); f_lo = b3; f_hi = 64; }                                             \
+        const int n_hi = (N0) + (nsteps - (N0)) * f_hi / 64;                                                      \
+        for (int n = (N0) + (nsteps - (N0)) * f_lo / 64; n < n_hi; n++) step(n, P, std::integral_constant<int, 3>{}); \
+      }                                                                                                           \
+    } else {                                                                                                      \
+      for (int n = (N0); n < nsteps; n++) step(n, P, std::integral_constant<int, 3>{});                          \
+    }
     Prefetched P;
     prefetch(P, A);
     WDPM_WAIT_ROWS(0);
@@ -642,14 +689,15 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
       // without it 4096^2 ran 4 % SLOWER (profiles/r03/warmup_stages_ab.txt)
       step(0, P, std::integral_constant<int, 1>{});      // nsteps >= 3: H >= 3
       step(1, P, std::integral_constant<int, 2>{});
-      for (int n = 2; n < nsteps; n++) step(n, P, std::integral_constant<int, 3>{});
+      WDPM_MARCH_FROM(2);
     } else {
-      for (int n = 0; n < nsteps; n++) step(n, P, std::integral_constant<int, 3>{});
+      WDPM_MARCH_FROM(0);
     }
     read_staged();
     write_staged(A + 3 * (nsteps - 1) - 4);    // the last step's rows
 #undef WDPM_WAIT_ROWS
 #undef WDPM_WAIT_W
+#undef WDPM_MARCH_FROM
   };
   if (edge) march(std::true_type{});
   else march(std::false_type{});
@@ -668,6 +716,15 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
     tf.zout[tile] = nzmask ? 0 : 1;
     atomicAdd(tf.active, 1u);
   }
+#ifdef WDPM_WAVE_TIMES
+  if (lane == 0 && item < 8192) {
+    __builtin_amdgcn_s_waitcnt(0);   // the wave's stores have left
+    g_wave_times[4 * item] = wt0;
+    g_wave_times[4 * item + 1] = wall_clock64();
+    g_wave_times[4 * item + 2] = __builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);  // HW_ID, XCC_ID
+    g_wave_times[4 * item + 3] = ((unsigned long long)strip << 32) | (unsigned)chunk;
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1219,8 +1276,19 @@ static int resident_waves() {
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, fused_iteration_kernel<MODULE, SZ_SAFE, DEM32>, 256, 0) != hipSuccess || blocks < 1)
     blocks = 2;
+  // never more than the kernel was built for: the chunk heights and every threshold of the dispatch were measured at that
+  // occupancy, and the register count an instantiation ends up with may allow more from one compiler run to the next
+  constexpr int built_for = (MODULE != 2 && DEM32 && !SZ_SAFE) ? WDPM_FUSED_CODES_WAVES : WDPM_FUSED_MIN_WAVES;
+  if (blocks > built_for) blocks = built_for;
   cached.store(cus * blocks * 4, std::memory_order_relaxed);
   return cus * blocks * 4;
+}
+
+/* WDPM_PLAIN_ADD=0: the tall-chunk add launches keep the centre gate (A/B) */
+static int env_plain_add() {
+  static std::atomic<int> v{-1};
+  if (v < 0) { const char *e = getenv("WDPM_PLAIN_ADD"); v = e ? atoi(e) : 1; }
+  return v;
 }
 
 /* WDPM_STORES=nt|plain forces the water raster's store policy (A/B); default 0 = by size and module */
@@ -1476,16 +1544,42 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
   if (fold_md) tf = TileFlags{nullptr, nullptr, 0, nullptr, nchunks};   /* every wave must look at its block: no skipping in this launch */
   if (fold_md && tiles) tiles->maintained = 0;
   const int store_plain = env_stores() == 2 || (env_stores() == 0 && module != 2 && (long long)(out_last - A0 + 1) * g.ncp >= 11000000LL);
-#define WDPM_LAUNCH(...) hipLaunchKernelGGL((fused_iteration_kernel<__VA_ARGS__>), grid, block, 0, s, w_in, w_out, dem, code, g, nstrips, nitems, H, A0, out_last, totaldrain, thres, module == 2 ? drain_owed : 0, tf, mda, store_plain)
+  // WDPM_LDS_PAD=<bytes> overrides the padding below (experiments)
+  static std::atomic<int> env_pad{-1};
+  if (env_pad < 0) { const char *e = getenv("WDPM_LDS_PAD"); env_pad = e ? atoi(e) : -2; }
+  // Two workgroups per CU, whatever the register allocator ends up with: the instantiations that stream DEM codes come out at
+  // 166 VGPRs with the priority loop (238 without), which would let the dispatcher stack three workgroups on some CUs and one
+  // on others.  36 KiB of unused dynamic LDS beside the 18 KiB of staging: two fit a CU's 160 KiB, three do not.
+  const int built_for = (module != 2 && dem32) ? WDPM_FUSED_CODES_WAVES : WDPM_FUSED_MIN_WAVES;
+  const unsigned lds_pad = env_pad.load(std::memory_order_relaxed) >= 0 ? (unsigned)env_pad.load(std::memory_order_relaxed)
+                                                                        : (built_for <= 2 ? 36864u : 0u);
+#define WDPM_LAUNCH(...) hipLaunchKernelGGL((fused_iteration_kernel<__VA_ARGS__>), grid, block, lds_pad, s, w_in, w_out, dem, code, g, nstrips, nitems, H, A0, out_last, totaldrain, thres, module == 2 ? drain_owed : 0, tf, mda, store_plain)
 #define WDPM_LAUNCH_FM(M, Z, D32) do { if (fold_md) { if (flush) WDPM_LAUNCH(M, Z, D32, true, true); else WDPM_LAUNCH(M, Z, D32, false, true); } \
                                        else { if (flush) WDPM_LAUNCH(M, Z, D32, true, false); else WDPM_LAUNCH(M, Z, D32, false, false); } } while (0)
-  if (module == 2 && fast && plain) WDPM_LAUNCH(2, false, false, false, false, true);
+  // tall chunks: the instantiations whose waves lower their issue priority as they advance (see the marching loop)
+  static std::atomic<int> env_prio{-1};
+  if (env_prio < 0) { const char *e = getenv("WDPM_PRIO"); env_prio = e ? atoi(e) : 1; }
+  const int nsteps = H / 3 + 2;
+  const bool prio = env_prio.load(std::memory_order_relaxed) != 0 && fast && !fold_md &&
+                    (nsteps >= (module == 2 ? 26 : 34) || env_prio.load(std::memory_order_relaxed) == 2);   // WDPM_PRIO=2: whatever the height (tests)
+  if (module == 2 && fast && plain) { if (prio) WDPM_LAUNCH(2, false, false, false, false, true, true); else WDPM_LAUNCH(2, false, false, false, false, true); }
+  else if (module == 2 && fast && prio) { if (flush) WDPM_LAUNCH(2, false, false, true, false, false, true); else WDPM_LAUNCH(2, false, false, false, false, false, true); }
   else if (module == 2 && fast) { if (flush) WDPM_LAUNCH(2, false, false, true, false); else WDPM_LAUNCH(2, false, false, false, false); }
   else if (module == 2) WDPM_LAUNCH(2, true, false, false, false);
+  else if (dem32 && prio && plain && env_plain_add()) WDPM_LAUNCH(0, false, true, false, false, true, true);
+  else if (dem32 && prio) { if (flush) WDPM_LAUNCH(0, false, true, true, false, false, true); else WDPM_LAUNCH(0, false, true, false, false, false, true); }
   else if (dem32) WDPM_LAUNCH_FM(0, false, true);
+  else if (fast && prio) { if (flush) WDPM_LAUNCH(0, false, false, true, false, false, true); else WDPM_LAUNCH(0, false, false, false, false, false, true); }
   else if (fast) WDPM_LAUNCH_FM(0, false, false);
   else WDPM_LAUNCH(0, true, false, false, false);
 #undef WDPM_LAUNCH_FM
 #undef WDPM_LAUNCH
   return hipGetLastError();
 }
+
+#ifdef WDPM_WAVE_TIMES
+extern "C" int wdpm_debug_wave_times(unsigned long long *out, int nwaves) {
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_times), (size_t)nwaves * 32) != hipSuccess;
+}
+#endif
