@@ -300,6 +300,9 @@ __device__ unsigned long long g_wave_times[4 * 8192];
 #ifndef WDPM_FUSED_MIN_WAVES
 #define WDPM_FUSED_MIN_WAVES 2   /* waves per SIMD the register allocator must leave room for */
 #endif
+#ifndef WDPM_PRIO_PEEL
+#define WDPM_PRIO_PEEL 1         /* add / subtract PRIO instantiations leave the dead stages of a chunk's first two steps out, as drain does */
+#endif
 #ifndef WDPM_XSEL
 #define WDPM_XSEL 0              /* 1: the PRIO instantiations' neighbour steps select through EXEC (wdpm_stencil.h::select_gt_exec):
                                     measured slower with the s_nop its hazard needs (profiles/r03/xsel_ab.txt), off */
@@ -682,7 +685,7 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
     Prefetched P;
     prefetch(P, A);
     WDPM_WAIT_ROWS(0);
-    if constexpr (MODULE == 2) {
+    if constexpr (MODULE == 2 || (PRIO && WDPM_PRIO_PEEL)) {
       // drain is bound by instruction issue (16 instructions per neighbour step): the dead stages of a chunk's first two
       // steps are left out (1-3 % at 4096^2, 5 % on the 1055-row slabs of 8 GPUs).  Add / subtract keep them: those
       // launches are bound by the memory system, the arithmetic of the first steps paces the waves' first requests, and
