@@ -1090,6 +1090,8 @@ relay_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
   const int R0 = A + 3 * wave;                    // this wave's rows R0 .. R0+2, later up to R0+4
   const int colb = c0 + 3 * lane;
   const size_t pitch = (size_t)g.ncp;
+  const bool rprio = (store_plain & 2) != 0;      // wave-uniform: see the stages
+  if (rprio) __builtin_amdgcn_s_setprio(3);       // the loads of a new workgroup go out ahead of an older one's arithmetic
   unsigned voff[3];
 #pragma unroll
   for (int j = 0; j < 3; j++) voff[j] = 8u * (unsigned)(colb + j < g.ncp ? colb + j : g.ncp - 1);
@@ -1187,6 +1189,12 @@ relay_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
       stage_lockstep<MODULE, 1, S0, 7, PLAIN>(W, D);                                                       \
     }                                                                                                      \
   } while (0)
+  // rprio (launches of a few rounds of workgroups: the host decides): a workgroup's issue priority falls from stage to stage, so that
+  // of the workgroups sharing a CU's SIMDs the one behind is served first (the arbiter's own rule is oldest first: see the marching
+  // loop).  profiles/r03/relay_prio_ab.txt: 1000^2 add 9.72 -> 9.11 us, drain 13.5 -> 12.0; 1200^2 and 1400^2 add +4.5 %; from five
+  // rounds of workgroups on nothing or a loss (1800^2 drain -4 %, add -10 %; 2400^2 add -10 %: there the old workgroups' early exit is
+  // what feeds the next round), so only launches of up to four rounds carry the flag
+  if (rprio) __builtin_amdgcn_s_setprio(2);
   WDPM_RELAY_STAGE(0);                                                        // oi = 1
 #pragma unroll
   for (int j = 0; j < 3; j++) {
@@ -1207,6 +1215,7 @@ relay_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
         D[4][j] = xdem[1][wave + 1][j * kLanes + lane];
       }
     }
+    if (rprio) __builtin_amdgcn_s_setprio(1);
     WDPM_RELAY_STAGE(1);                                                      // oi = 2
   }
 #pragma unroll
@@ -1216,6 +1225,7 @@ relay_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
   if (MODULE == 2 && wo[1] >= 0) ds.td = td_sh[1];
 #pragma unroll
   for (int j = 0; j < 3; j++) W[4][j] = xch[1][wave + 1][j * kLanes + lane];
+  if (rprio) __builtin_amdgcn_s_setprio(0);
   WDPM_RELAY_STAGE(2);                                                        // oi = 3
 #undef WDPM_RELAY_STAGE
   // wave w stores rows A+3w+2 .. A+3w+4 (wave 0 also rows 0, 1 of the raster's first chunk)
@@ -1240,7 +1250,7 @@ relay_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
       for (int kk = 0; kk < 3; kk++) {
         const int c = lo + 64 * kk + lane < hi ? lo + 64 * kk + lane : hi;
         double *const q = wout + (size_t)r * pitch + c0 + c;
-        if (store_plain) *q = t[i][c];
+        if (store_plain & 1) *q = t[i][c];
         else __builtin_nontemporal_store(t[i][c], q);
       }
     }
@@ -1440,7 +1450,11 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
                              env_relay == 2);
       if (env_relay && !fold_md && relay_ok) {
         const dim3 rgrid(((unsigned)nwg + 7) / 8 * 8), rblock(tall ? 512 : 256);
-        const int relay_plain = env_stores() == 2 || (env_stores() == 0 && module != 2 && tall && r8 >= 6);   // 2000^2 25.8 -> 25.1 us, 3000^2 50.1 -> 46.1
+        int relay_plain = env_stores() == 2 || (env_stores() == 0 && module != 2 && tall && r8 >= 6);   // 2000^2 25.8 -> 25.1 us, 3000^2 50.1 -> 46.1
+        // bit 1: stage priorities, where workgroups share SIMDs and the launch is a few rounds long (see the kernel; WDPM_RELAY_PRIO=0/2: never / always)
+        static std::atomic<int> env_rprio{-1};
+        if (env_rprio < 0) { const char *t = getenv("WDPM_RELAY_PRIO"); env_rprio = t ? atoi(t) : 1; }
+        if (env_rprio == 2 || (env_rprio == 1 && nwg > cus && (tall ? r8 : r4) <= 4)) relay_plain |= 2;
 #define WDPM_RELAY_LAUNCH(...) hipLaunchKernelGGL((relay_iteration_kernel<__VA_ARGS__>), rgrid, rblock, 0, s, w_in, w_out, dem, g, nstr, (int)nwg, A0, out_last, thres, totaldrain, module == 2 ? drain_owed : 0, code, relay_plain)
 #define WDPM_RELAY_PICK(NW)                                                                                        \
         do {                                                                                                       \
