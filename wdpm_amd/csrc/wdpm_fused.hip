@@ -296,6 +296,10 @@ __device__ __forceinline__ void three_stages(double (&W)[7][3], const double (&D
 
 #ifdef WDPM_WAVE_TIMES   /* timing builds only (tools/wave_times.py): when each wave of the marching kernel starts and ends, and where */
 __device__ unsigned long long g_wave_times[4 * 8192];
+/* relay kernel: eight stamps per wave (tools/relay_times.py); the wait in front of each makes the stamp mean "everything before is done" */
+#define WDPM_RSTAMP(k) do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0); rst[k] = wall_clock64(); __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define WDPM_RSTAMP(k) do { } while (0)
 #endif
 #ifndef WDPM_FUSED_MIN_WAVES
 #define WDPM_FUSED_MIN_WAVES 2   /* waves per SIMD the register allocator must leave room for */
@@ -1090,6 +1094,10 @@ relay_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
   const int R0 = A + 3 * wave;                    // this wave's rows R0 .. R0+2, later up to R0+4
   const int colb = c0 + 3 * lane;
   const size_t pitch = (size_t)g.ncp;
+#ifdef WDPM_WAVE_TIMES
+  unsigned long long rst[8];
+  rst[0] = wall_clock64();
+#endif
   const bool rprio = (store_plain & 2) != 0;      // wave-uniform: see the stages
   if (rprio) __builtin_amdgcn_s_setprio(3);       // the loads of a new workgroup go out ahead of an older one's arithmetic
   unsigned voff[3];
@@ -1195,7 +1203,9 @@ relay_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
   // rounds of workgroups on nothing or a loss (1800^2 drain -4 %, add -10 %; 2400^2 add -10 %: there the old workgroups' early exit is
   // what feeds the next round), so only launches of up to four rounds carry the flag
   if (rprio) __builtin_amdgcn_s_setprio(2);
+  WDPM_RSTAMP(1);                                                             // rows loaded
   WDPM_RELAY_STAGE(0);                                                        // oi = 1
+  WDPM_RSTAMP(2);
 #pragma unroll
   for (int j = 0; j < 3; j++) {
     xch[0][wave][j * kLanes + lane] = W[0][j];
@@ -1205,6 +1215,7 @@ relay_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
     }
   }
   __syncthreads();
+  WDPM_RSTAMP(3);
   if (MODULE == 2 && wo[0] >= 0) ds.td = td_sh[0];
   if (wave < NW - 1) {
 #pragma unroll
@@ -1218,15 +1229,24 @@ relay_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
     if (rprio) __builtin_amdgcn_s_setprio(1);
     WDPM_RELAY_STAGE(1);                                                      // oi = 2
   }
+  WDPM_RSTAMP(4);
 #pragma unroll
   for (int j = 0; j < 3; j++) xch[1][wave][j * kLanes + lane] = W[1][j];
   __syncthreads();
+  WDPM_RSTAMP(5);
+#ifdef WDPM_WAVE_TIMES
+  if (wave >= NW - 2 && lane == 0) {
+    const int wid = ((int)blockIdx.x * NW + wave);
+    if (wid < 4096) { for (int k = 0; k < 6; k++) g_wave_times[8 * wid + k] = rst[k]; g_wave_times[8 * wid + 6] = rst[5]; g_wave_times[8 * wid + 7] = rst[5]; }
+  }
+#endif
   if (wave >= NW - 2) return;
   if (MODULE == 2 && wo[1] >= 0) ds.td = td_sh[1];
 #pragma unroll
   for (int j = 0; j < 3; j++) W[4][j] = xch[1][wave + 1][j * kLanes + lane];
   if (rprio) __builtin_amdgcn_s_setprio(0);
   WDPM_RELAY_STAGE(2);                                                        // oi = 3
+  WDPM_RSTAMP(6);
 #undef WDPM_RELAY_STAGE
   // wave w stores rows A+3w+2 .. A+3w+4 (wave 0 also rows 0, 1 of the raster's first chunk)
   if (LDSDEM) {
@@ -1267,6 +1287,13 @@ relay_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
   }
   // the wave that ran the last alignment's outlet block holds the final value; if that alignment had none here, wave 0 does
   if (MODULE == 2 && owner && lane == 0 && wave == (wo[2] >= 0 ? wo[2] : 0)) *totaldrain = ds.td;
+#ifdef WDPM_WAVE_TIMES
+  WDPM_RSTAMP(7);
+  if (lane == 0) {
+    const int wid = ((int)blockIdx.x * NW + wave);
+    if (wid < 4096) for (int k = 0; k < 8; k++) g_wave_times[8 * wid + k] = rst[k];
+  }
+#endif
 }
 
 __global__ void dpp_probe_kernel(int *out) {
