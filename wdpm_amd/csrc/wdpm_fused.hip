@@ -1534,7 +1534,7 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
               : fast      ? resident_waves<0, false>()
                           : resident_waves<0, true>();
   {
-    // The kernel is HBM-bound with ONE wave per SIMD already; a second wave per SIMD only adds
+    // (Round 1, fp64 DEM:) the kernel is bound by the memory system with ONE wave per SIMD already; a second wave per SIMD only adds
     // concurrent DRAM row streams and, on rasters too small to fill the chip, makes the dispatcher
     // double up waves on some SIMDs while others idle.  Filling half of the resident slots measured
     // +4 % at 16384^2, +13 % at 6000^2, x1.9 at 1500^2, x2.3 at 1024^2 (-4 % at 4096^2).
