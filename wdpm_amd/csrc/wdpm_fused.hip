@@ -341,7 +341,11 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
   // speed matter, never correctness): give each XCD a contiguous run of work items so that the
   // halo columns shared by neighbouring strips hit in its L2 (+2 % measured).  gridDim.x is a
   // multiple of 8, so b -> (b % 8) * (gridDim.x / 8) + b / 8 is a permutation of the blocks.
+#ifdef WDPM_XCD_REVERSE   /* timing experiments: XCD x takes the raster's band 7 - x (does a slow XCD stay slow, or the band?) */
+  const int vb = (7 - blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8;
+#else
   const int vb = (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8;
+#endif
   // the wave number is the same in all 64 lanes: say so, and everything derived from it (strip,
   // chunk, row bases, loop bounds) lives in SGPRs and is computed on the scalar unit
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
