@@ -22,7 +22,7 @@ with lib.context(module=module, nrows=n, ncols=n, missingvalue=-99999.0, kernel=
     for rep in range(3):
         c.iterate(50); c.synchronize()
         buf = np.zeros((4096, 8), dtype=np.uint64)
-        assert raw.wdpm_debug_wave_times(buf.ctypes.data_as(ctypes.c_void_p), 8192) == 0
+        assert raw.wdpm_debug_relay_times(buf.ctypes.data_as(ctypes.c_void_p), 8192) == 0
         t = buf[(buf[:, 0] > 0) & (buf[:, 7] >= buf[:, 0]) & (buf[:, 7] - buf[:, 0] < 10**7)].astype(np.int64)
         base = t[:, 0].min(); u = (t - base) / 100.0
         print(f"== {n}x{n} {module}, launch {rep}: {len(t)} waves, span {u[:, 7].max():.2f} us")

@@ -295,7 +295,7 @@ __device__ __forceinline__ void three_stages(double (&W)[7][3], const double (&D
 }
 
 #ifdef WDPM_WAVE_TIMES   /* timing builds only (tools/wave_times.py): when each wave of the marching kernel starts and ends, and where */
-__device__ unsigned long long g_wave_times[4 * 8192];
+static __device__ unsigned long long g_wave_times[4 * 8192];   /* one per translation unit (WDPM_TU): each has its accessor */
 /* relay kernel: eight stamps per wave (tools/relay_times.py); the wait in front of each makes the stamp mean "everything before is done" */
 #define WDPM_RSTAMP(k) do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0); rst[k] = wall_clock64(); __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
@@ -1391,34 +1391,17 @@ static hipError_t dpp_selfcheck(hipStream_t s) {
   return ok ? hipSuccess : hipErrorUnknown;
 }
 
-hipError_t wdpm_launch_fused(int module, const double *w_in, double *w_out, const double *dem, const DemCode &code,
-                             const SlabGeom &g, int chunk_rows, int signed_zero_safe, const double *flush,
-                             int drain_owed, double *totaldrain, hipStream_t s, TilePlan *tiles, const MaxDiffArgs *md,
-                             int plain_water) {
-  return wdpm_launch_fused_rows(module, w_in, w_out, dem, code, g, 0, g.rows - 1, chunk_rows, signed_zero_safe, flush,
-                                drain_owed, totaldrain, s, tiles, md, 0, plain_water);
-}
-
-/* one iteration restricted to the output rows [A0 + 2 (0 when A0 == 0), out_last]; A0 % 3 == 0 */
-hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out, const double *dem,
-                                  const DemCode &code, const SlabGeom &g, int A0, int out_last, int chunk_rows,
-                                  int signed_zero_safe, const double *flush, int drain_owed, double *totaldrain,
-                                  hipStream_t s, TilePlan *tiles, const MaxDiffArgs *md, int leave_cus, int plain_water) {
-  if (tiles) tiles->maintained = 0;
-  /* The gate-free variants (PLAIN, see block_update) exist for the launches between a block's first (flush on load) and last
-   * (max diff) - of the drain module, which is bound by instruction issue (+4.5 % at 8192^2, +3.8 % at 4096^2), and of the
-   * triangle kernel (+3 % at 482^2).  The marching add / subtract kernel keeps its gate: 35 of 1001 instructions per step
-   * less changed nothing at 16384^2 and 8192^2 and cost 1 % at 4096^2 (profiles/r03/plain_water_ab.txt; DESIGN.md §4.1: that
-   * launch is bound by the memory system and by instruction issue alike). */
-  const bool plain = plain_water && !signed_zero_safe && !flush && !(md && md->old);
-  const bool fold_md = md && md->old && module != 2 && !signed_zero_safe;
-  if (md && md->old && !fold_md) return hipErrorInvalidValue;     /* the caller asks only where a folding variant exists */
-  hipError_t e = dpp_selfcheck(s);
-  if (e != hipSuccess) return e;
-  if (A0 < 0 || A0 % 3 != 0 || out_last > g.rows - 1 || out_last < A0) return hipErrorInvalidValue;
-  if (flush && signed_zero_safe) return hipErrorInvalidValue;   /* the caller flushes in place for that variant */
-  const double thres = flush ? *flush : 0.0;
-  {
+/* The launches of small and mid-size rasters (relay and triangle kernels): *taken says whether one was queued.  Compiled as a
+ * translation unit of its own (WDPM_TU == 2; the marching kernel and everything else: WDPM_TU == 1), because the two want different
+ * instruction schedulers: the marching kernel is 2 % faster under the compiler's max-ILP strategy (-mllvm -amdgpu-sched-strategy=max-ilp:
+ * add 16384^2 1.1425 -> 1.1189 ms), the eight-wave relay instantiations 2.4 % slower (profiles/r03/sched_strategy_ab.txt). */
+hipError_t wdpm_launch_small_rows(int module, const double *w_in, double *w_out, const double *dem, const DemCode &code,
+                                  const SlabGeom &g, int A0, int out_last, int chunk_rows, int signed_zero_safe, bool flush,
+                                  double thres, int drain_owed, double *totaldrain, hipStream_t s, TilePlan *tiles,
+                                  const MaxDiffArgs *md, bool fold_md, bool plain, bool *taken)
+#if !defined(WDPM_TU) || WDPM_TU == 2
+{
+  *taken = false;
     // Small launches: if every 3-row chunk of the window fits on the chip at once, the triangle kernel's six
     // lockstep stages beat the marching kernel's nine dependent ones (482 x 471: DESIGN.md §4.1c).
     // WDPM_TRI=0 keeps the marching kernel (A/B runs), WDPM_TRI=2 forces the triangle kernel on any size.
@@ -1501,6 +1484,7 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
         } else if (tall) WDPM_RELAY_PICK(8); else WDPM_RELAY_PICK(4);
 #undef WDPM_RELAY_PICK
 #undef WDPM_RELAY_LAUNCH
+        *taken = true;
         return hipGetLastError();
       }
     }
@@ -1520,8 +1504,48 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
       else if (two) { if (flush) WDPM_TRI_LAUNCH(0, true, 2); else if (plain) WDPM_TRI_LAUNCH(0, false, 2, true); else WDPM_TRI_LAUNCH(0, false, 2); }
       else { if (flush) WDPM_TRI_LAUNCH(0, true); else if (plain) WDPM_TRI_LAUNCH(0, false, 1, true); else WDPM_TRI_LAUNCH(0, false); }
 #undef WDPM_TRI_LAUNCH
+      *taken = true;
       return hipGetLastError();
     }
+    return hipSuccess;
+}
+#else
+;
+#endif
+
+#if !defined(WDPM_TU) || WDPM_TU == 1
+hipError_t wdpm_launch_fused(int module, const double *w_in, double *w_out, const double *dem, const DemCode &code,
+                             const SlabGeom &g, int chunk_rows, int signed_zero_safe, const double *flush,
+                             int drain_owed, double *totaldrain, hipStream_t s, TilePlan *tiles, const MaxDiffArgs *md,
+                             int plain_water) {
+  return wdpm_launch_fused_rows(module, w_in, w_out, dem, code, g, 0, g.rows - 1, chunk_rows, signed_zero_safe, flush,
+                                drain_owed, totaldrain, s, tiles, md, 0, plain_water);
+}
+
+/* one iteration restricted to the output rows [A0 + 2 (0 when A0 == 0), out_last]; A0 % 3 == 0 */
+hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out, const double *dem,
+                                  const DemCode &code, const SlabGeom &g, int A0, int out_last, int chunk_rows,
+                                  int signed_zero_safe, const double *flush, int drain_owed, double *totaldrain,
+                                  hipStream_t s, TilePlan *tiles, const MaxDiffArgs *md, int leave_cus, int plain_water) {
+  if (tiles) tiles->maintained = 0;
+  /* The gate-free variants (PLAIN, see block_update) exist for the launches between a block's first (flush on load) and last
+   * (max diff) - of the drain module, which is bound by instruction issue (+4.5 % at 8192^2, +3.8 % at 4096^2), and of the
+   * triangle kernel (+3 % at 482^2).  The marching add / subtract kernel keeps its gate: 35 of 1001 instructions per step
+   * less changed nothing at 16384^2 and 8192^2 and cost 1 % at 4096^2 (profiles/r03/plain_water_ab.txt; DESIGN.md §4.1: that
+   * launch is bound by the memory system and by instruction issue alike). */
+  const bool plain = plain_water && !signed_zero_safe && !flush && !(md && md->old);
+  const bool fold_md = md && md->old && module != 2 && !signed_zero_safe;
+  if (md && md->old && !fold_md) return hipErrorInvalidValue;     /* the caller asks only where a folding variant exists */
+  hipError_t e = dpp_selfcheck(s);
+  if (e != hipSuccess) return e;
+  if (A0 < 0 || A0 % 3 != 0 || out_last > g.rows - 1 || out_last < A0) return hipErrorInvalidValue;
+  if (flush && signed_zero_safe) return hipErrorInvalidValue;   /* the caller flushes in place for that variant */
+  const double thres = flush ? *flush : 0.0;
+  {
+    bool taken = false;
+    e = wdpm_launch_small_rows(module, w_in, w_out, dem, code, g, A0, out_last, chunk_rows, signed_zero_safe, flush != nullptr, thres,
+                               drain_owed, totaldrain, s, tiles, md, fold_md, plain, &taken);
+    if (taken || e != hipSuccess) return e;
   }
   int nstrips = 1;
   if (g.ncp > kStripIn - kHaloR) nstrips = (g.ncp - (kStripIn - kHaloR) + kStripOut - 1) / kStripOut + 1;
@@ -1625,9 +1649,19 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
   return hipGetLastError();
 }
 
+#endif   /* WDPM_TU 1 */
+
 #ifdef WDPM_WAVE_TIMES
+#if !defined(WDPM_TU) || WDPM_TU == 1
 extern "C" int wdpm_debug_wave_times(unsigned long long *out, int nwaves) {
   if (hipDeviceSynchronize() != hipSuccess) return 1;
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_times), (size_t)nwaves * 32) != hipSuccess;
 }
+#endif
+#if !defined(WDPM_TU) || WDPM_TU == 2
+extern "C" int wdpm_debug_relay_times(unsigned long long *out, int nwaves) {
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_times), (size_t)nwaves * 32) != hipSuccess;
+}
+#endif
 #endif
