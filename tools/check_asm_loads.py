@@ -143,6 +143,13 @@ def main():
         for r in check(name, body) + check_exec_dpp(body):
             print(f"{name[:60]}: {r}")
             bad += 1
+    # round 4: no kernel of this file may spill - a hot instantiation that went to scratch would still pass every
+    # parity test.  The metadata lists .name / .private_segment_fixed_size per kernel.
+    text = "\n".join(lines)
+    for m in re.finditer(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)", text):
+        if int(m.group(2)):
+            print(f"{m.group(1)[:100]}: {m.group(2)} bytes of scratch")
+            bad += 1
     print("asm prefetch check:", "OK" if not bad else f"{bad} violations")
     sys.exit(1 if bad else 0)
 

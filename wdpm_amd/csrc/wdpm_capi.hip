@@ -281,7 +281,7 @@ int wdpm_create(wdpm_ctx **out, const wdpm_params *p) {
   x->drain_owed = false;
   x->flush_thres = -__builtin_inf();
   x->d_scal = nullptr; x->d_bits = nullptr; x->h_pin = nullptr; x->d_stat = nullptr;
-  x->d_dem32 = nullptr; x->code = DemCode{nullptr, 0.0, 1.0, 1.0, 0}; x->dem32_encodable = false;
+  x->d_dem32 = nullptr; x->code = DemCode{nullptr, 0.0, 1.0, 1.0, 0}; x->dem32_encodable = false; x->dem_bounded = false;
   x->d_sum_approx = nullptr; x->d_sum_i = nullptr; x->d_sum_k = nullptr; x->d_sum_flag = nullptr;
   x->own_stream = true;
   x->side = nullptr; x->ev_fork = nullptr; x->ev_join = nullptr; x->pending_join = false; x->ev_copy[0] = x->ev_copy[1] = nullptr;
@@ -301,7 +301,7 @@ int wdpm_create(wdpm_ctx **out, const wdpm_params *p) {
   if (e == hipSuccess) e = guarded_malloc(x, (void **)&x->d_w[2], bytes + 64 * sizeof(double));
   if (e == hipSuccess) e = guarded_malloc(x, (void **)&x->d_dem32, x->cells * sizeof(int) + 64);
   if (e == hipSuccess) e = hipMalloc(&x->d_scal, 2 * sizeof(double));
-  if (e == hipSuccess) e = hipMalloc(&x->d_bits, sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipMalloc(&x->d_bits, 2 * sizeof(unsigned long long));
   if (e == hipSuccess) e = hipMalloc(&x->d_md, sizeof(unsigned long long));
   {
     /* tile flags: strips of 171 columns x chunks of >= 6 rows */
@@ -386,6 +386,14 @@ static void flushed_whole(wdpm_ctx *x, double thres) {
   if (thres >= 0.0) x->w_negative = false;
 }
 
+/* wdpm_kernels.h: WDPM_LAUNCH_PLAIN | WDPM_LAUNCH_CLAMP_OK for the iteration launches of this context */
+static bool plain_water(const wdpm_ctx *x);
+static int launch_flags(const wdpm_ctx *x) {
+  static std::atomic<int> env{-1};
+  if (env < 0) { const char *e = getenv("WDPM_CLAMP"); env = e ? atoi(e) : 1; }      /* WDPM_CLAMP=0: the unclamped neighbour step everywhere (A/B, tests) */
+  return (plain_water(x) ? WDPM_LAUNCH_PLAIN : 0) | (env != 0 && x->dem_bounded ? WDPM_LAUNCH_CLAMP_OK : 0);
+}
+
 static bool plain_water(const wdpm_ctx *x) {
   static std::atomic<int> env{-1};
   if (env < 0) { const char *e = getenv("WDPM_PLAIN"); env = e ? atoi(e) : 1; }      /* WDPM_PLAIN=0: gated variants only (A/B, tests) */
@@ -396,15 +404,18 @@ static bool plain_water(const wdpm_ctx *x) {
  * (e = 0..6, the smallest that works; real DEMs are decimal text).  The device checks every cell
  * with the decoder the iteration kernel uses; any miss leaves the fp64 DEM in charge. */
 static int encode_dem(wdpm_ctx *x) {
-  x->dem32_encodable = false;
+  x->dem32_encodable = false; x->dem_bounded = false;
+  x->dem_bounded = false;
   x->code.q = nullptr;
+  HIP_TRY(wdpm_launch_dem_min(x->d_dem, x->cells, x->d_bits, x->stream));
+  HIP_TRY(hipMemcpyAsync(x->h_pin, x->d_bits, 2 * sizeof(double), hipMemcpyDeviceToHost, x->stream));
+  if (wdpm_stream_sync(x, x->stream)) return 1;
+  unsigned long long key, amax;
+  memcpy(&key, x->h_pin, sizeof key);
+  memcpy(&amax, x->h_pin + 1, sizeof amax);
+  x->dem_bounded = amax < 0x41d0000000000000ull;               /* |dem| < 2^30 on every valid cell (none at all: 0) */
   const char *env = getenv("WDPM_DEM32");
   if (env && atoi(env) == 0) return 0;
-  HIP_TRY(wdpm_launch_dem_min(x->d_dem, x->cells, x->d_bits, x->stream));
-  HIP_TRY(hipMemcpyAsync(x->h_pin, x->d_bits, sizeof(double), hipMemcpyDeviceToHost, x->stream));
-  if (wdpm_stream_sync(x, x->stream)) return 1;
-  unsigned long long key;
-  memcpy(&key, x->h_pin, sizeof key);
   if (key == ~0ull) return 0;                                  /* no valid cell at all */
   const double vmin = wdpm_dem_key_to_double(key);
   static const double p10[7] = {1.0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6};
@@ -693,7 +704,11 @@ int wdpm_water_ptr(wdpm_ctx *x, void **ptr) {
   *ptr = x->d_w[x->cur];
   return 0;
 }
-int wdpm_dem_ptr(wdpm_ctx *x, void **ptr) { *ptr = x->d_dem; return 0; }
+int wdpm_dem_ptr(wdpm_ctx *x, void **ptr) {
+  x->dem_bounded = false;                        /* the caller may write anything through it */
+  *ptr = x->d_dem;
+  return 0;
+}
 
 /* ---- block loop ------------------------------------------------------------------------- */
 int wdpm_begin_block(wdpm_ctx *x, double thres) {
@@ -797,7 +812,7 @@ int wdpm_iterate(wdpm_ctx *x, int32_t n_iter) {
       HIP_TRY(wdpm_launch_fused(x->p.module, x->d_w[x->cur], x->d_w[t], x->d_dem, x->code, x->g, chunk_rows,
                                 x->signed_zero_safe ? 1 : 0, x->flush_pending ? &x->flush_thres : nullptr,
                                 x->drain_owed ? 1 : 0, x->d_scal, x->stream, track ? &tp : nullptr, md.old ? &md : nullptr,
-                                plain_water(x) ? 1 : 0));
+                                launch_flags(x)));
       if (x->flush_pending) flushed_whole(x, x->flush_thres);   /* the launch flushed every value it loaded, and it loaded them all */
       if (md.old) x->md_valid = true;
       if (track && tp.maintained) {
@@ -862,7 +877,7 @@ int wdpm_iterate_overlapped(wdpm_ctx *x, int32_t n_iter, int32_t top_rows, int32
   double *w_out = x->d_w[t_slot];
   const int szs = x->signed_zero_safe ? 1 : 0;
   const double *flush = x->flush_pending ? &x->flush_thres : nullptr;
-  const int plain = plain_water(x) ? 1 : 0;
+  const int plain = launch_flags(x);
   const bool fold = x->md_hint && !x->signed_zero_safe;     /* (usable: fused kernel, not the drain module) */
   x->md_hint = x->md_valid = false;
   MaxDiffArgs md{fold ? x->d_w[x->old] : nullptr, x->flush_thres, x->md_lo, x->md_hi, x->d_md};

@@ -66,6 +66,8 @@ struct wdpm_ctx {
   int *d_dem32;                 /* the DEM as verified-lossless 32-bit codes (wdpm_kernels.h::DemCode) */
   DemCode code;                 /* code.q == d_dem32 while the uploaded DEM is encodable and the option is on */
   bool dem32_encodable;
+  bool dem_bounded;             /* every valid elevation of the uploaded DEM is below 2^30 m in magnitude (scan_dem): the clamped
+                                   neighbour step may run where the depths allow it (wdpm_kernels.h: WDPM_LAUNCH_CLAMP_OK) */
   /* wdpm_iterate_overlapped: side stream for the interior launch and the event that joins it */
   hipStream_t side;
   hipEvent_t ev_fork, ev_join;

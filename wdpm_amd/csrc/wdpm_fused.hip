@@ -122,7 +122,8 @@ __device__ __forceinline__ void step_drain(const double dc, double &wc, const do
  * max(ht / 8, -0.0) = +-0; NODATA centre (dem = +inf): inf > en gives x = w_c = 0, and next to a NODATA neighbour ht is NaN,
  * which v_max turns into -0.0 - and w + (+-0) == w, w - |+-0| == w for every w that is not -0.0.  (drain: the same through
  * min(max(x / 8, -0.0), w_c = 0).)  Four instructions per block less for add, eight for drain. */
-/* FLAGS: bit 0 = PLAIN, bit 1 = XSEL (wdpm_stencil.h::select_gt_exec) */
+/* FLAGS: bit 0 = PLAIN, bit 1 = CLAMP (wdpm_stencil.h::eighth_clamped: the caller knows that no depth of this block exceeds 8 m
+ * during the pass - see `deep` in the marching kernel; never on the outlet's path) */
 template <int MODULE, bool SZ_SAFE, bool OUTLET = true, int FLAGS = 0>
 __device__ __forceinline__ void block_update(
     double &w00, double &w01, double &w02, double &w10, double &w11, double &w12, double &w20, double &w21,
@@ -130,29 +131,29 @@ __device__ __forceinline__ void block_update(
     const double d12, const double d20, const double d21, const double d22,
     const bool rd0, const bool rd1, const bool rd2, const bool cd0, const bool cd1, const bool cd2,
     DrainState &ds) {
-  constexpr bool PLAIN = (FLAGS & 1) != 0, XS = (FLAGS & 2) != 0;
+  constexpr bool PLAIN = (FLAGS & 1) != 0, CL = (FLAGS & 2) != 0;
   double wc = w11;
   bool gate = (wc > 0.0) & (d11 < WDPM_INF);            // WDPMCL.c:1099
   if (MODULE == 2 && !OUTLET && !SZ_SAFE && PLAIN) {
-    flow_drain_nz<XS>(d11, wc, d00, w00);
-    flow_drain_nz<XS>(d11, wc, d01, w01);
-    flow_drain_nz<XS>(d11, wc, d02, w02);
-    flow_drain_nz<XS>(d11, wc, d10, w10);
-    flow_drain_nz<XS>(d11, wc, d12, w12);
-    flow_drain_nz<XS>(d11, wc, d20, w20);
-    flow_drain_nz<XS>(d11, wc, d21, w21);
-    flow_drain_nz<XS>(d11, wc, d22, w22);
+    flow_drain_nz<CL>(d11, wc, d00, w00);
+    flow_drain_nz<CL>(d11, wc, d01, w01);
+    flow_drain_nz<CL>(d11, wc, d02, w02);
+    flow_drain_nz<CL>(d11, wc, d10, w10);
+    flow_drain_nz<CL>(d11, wc, d12, w12);
+    flow_drain_nz<CL>(d11, wc, d20, w20);
+    flow_drain_nz<CL>(d11, wc, d21, w21);
+    flow_drain_nz<CL>(d11, wc, d22, w22);
   } else if (MODULE == 2 && !OUTLET && !SZ_SAFE) {
     const double dce = gate ? d11 : -WDPM_INF;           // see flow_drain_nz
     wc = gate ? wc : 0.0;                                // its clamp needs a centre depth >= +0
-    flow_drain_nz<XS>(dce, wc, d00, w00);
-    flow_drain_nz<XS>(dce, wc, d01, w01);
-    flow_drain_nz<XS>(dce, wc, d02, w02);
-    flow_drain_nz<XS>(dce, wc, d10, w10);
-    flow_drain_nz<XS>(dce, wc, d12, w12);
-    flow_drain_nz<XS>(dce, wc, d20, w20);
-    flow_drain_nz<XS>(dce, wc, d21, w21);
-    flow_drain_nz<XS>(dce, wc, d22, w22);
+    flow_drain_nz<CL>(dce, wc, d00, w00);
+    flow_drain_nz<CL>(dce, wc, d01, w01);
+    flow_drain_nz<CL>(dce, wc, d02, w02);
+    flow_drain_nz<CL>(dce, wc, d10, w10);
+    flow_drain_nz<CL>(dce, wc, d12, w12);
+    flow_drain_nz<CL>(dce, wc, d20, w20);
+    flow_drain_nz<CL>(dce, wc, d21, w21);
+    flow_drain_nz<CL>(dce, wc, d22, w22);
     wc = gate ? wc : w11;
   } else if (MODULE == 2 && !OUTLET) {
     flow_drain(d11, wc, d00, w00, gate);
@@ -185,7 +186,7 @@ __device__ __forceinline__ void block_update(
         wc = hit ? 0.0 : wc;                             // :1984
         hit_any = hit_any | hit;
       }
-      flow_drain_nz<XS>(dce, wc, dn, wn);                    // :1988-2000
+      flow_drain_nz<false>(dce, wc, dn, wn);                 // :1988-2000 (never clamped: the outlet's path is off the hot path)
     };
     nb(d00, w00, rd0, any0, cd0);
     nb(d01, w01, rd0, any1, cd1);
@@ -216,14 +217,14 @@ __device__ __forceinline__ void block_update(
   } else if (!SZ_SAFE) {
     // no -0.0 in the raster: the gate rides on the centre elevation (see flow_add_nz) - or is not needed at all (PLAIN)
     const double dce = PLAIN ? d11 : (gate ? d11 : -WDPM_INF);
-    flow_add_nz<XS>(dce, wc, d00, w00);
-    flow_add_nz<XS>(dce, wc, d01, w01);
-    flow_add_nz<XS>(dce, wc, d02, w02);
-    flow_add_nz<XS>(dce, wc, d10, w10);
-    flow_add_nz<XS>(dce, wc, d12, w12);
-    flow_add_nz<XS>(dce, wc, d20, w20);
-    flow_add_nz<XS>(dce, wc, d21, w21);
-    flow_add_nz<XS>(dce, wc, d22, w22);
+    flow_add_nz<CL>(dce, wc, d00, w00);
+    flow_add_nz<CL>(dce, wc, d01, w01);
+    flow_add_nz<CL>(dce, wc, d02, w02);
+    flow_add_nz<CL>(dce, wc, d10, w10);
+    flow_add_nz<CL>(dce, wc, d12, w12);
+    flow_add_nz<CL>(dce, wc, d20, w20);
+    flow_add_nz<CL>(dce, wc, d21, w21);
+    flow_add_nz<CL>(dce, wc, d22, w22);
   } else {
     flow_add(d11, wc, d00, w00, gate);
     flow_add(d11, wc, d01, w01, gate);
@@ -307,10 +308,6 @@ static __device__ unsigned long long g_wave_times[4 * 8192];   /* one per transl
 #ifndef WDPM_PRIO_PEEL
 #define WDPM_PRIO_PEEL 1         /* add / subtract PRIO instantiations leave the dead stages of a chunk's first two steps out, as drain does */
 #endif
-#ifndef WDPM_XSEL
-#define WDPM_XSEL 0              /* 1: the PRIO instantiations' neighbour steps select through EXEC (wdpm_stencil.h::select_gt_exec):
-                                    measured slower with the s_nop its hazard needs (profiles/r03/xsel_ab.txt), off */
-#endif
 #ifndef WDPM_PRIO_OLD            /* PRIO instantiations: where a wave's issue priority drops a level, in 64ths of its chunk - see the marching loop */
 #define WDPM_PRIO_OLD 18, 45, 56
 #define WDPM_PRIO_YOUNG 37, 49, 62
@@ -329,13 +326,20 @@ struct Prefetched {
   int qe[3][3];
 };
 
+/* waves per SIMD an instantiation is built for.  The drain variant for rasters that hold a -0.0 depth (SZ_SAFE: the reference's
+ * conditional 21-instruction step) does not fit two waves' 256 VGPRs - it spilled 12 bytes in round 3 - and is built for one. */
+template <int MODULE, bool SZ_SAFE, bool DEM32, bool MD>
+constexpr int fused_built_for() {
+  return (MODULE == 2 && SZ_SAFE) ? 1 : (MODULE != 2 && DEM32 && !MD && !SZ_SAFE) ? WDPM_FUSED_CODES_WAVES : WDPM_FUSED_MIN_WAVES;
+}
+
 template <int MODULE, bool SZ_SAFE, bool DEM32, bool FLUSH = false, bool MD = false, bool PLAIN = false, bool PRIO = false>
-__global__ void __launch_bounds__(256, (MODULE != 2 && DEM32 && !MD && !SZ_SAFE) ? WDPM_FUSED_CODES_WAVES : WDPM_FUSED_MIN_WAVES)
+__global__ void __launch_bounds__(256, (fused_built_for<MODULE, SZ_SAFE, DEM32, MD>()))
 fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout,
                        const double *__restrict__ dem, const DemCode code, const SlabGeom g, const int nstrips,
                        const int nitems, const int H, const int A0, const int out_last,
                        double *__restrict__ totaldrain, const double thres, const int drain_owed,
-                       const TileFlags tf, const MaxDiffArgs md, const int store_plain) {
+                       const TileFlags tf, const MaxDiffArgs md, const int store_plain, const int no_clamp) {
   const int lane = threadIdx.x & 63;
   // Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2; placement is only a
   // speed matter, never correctness): give each XCD a contiguous run of work items so that the
@@ -395,6 +399,15 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
     }
   }
   unsigned long long nzmask = 0;        // lanes that staged a value other than 0.0 (no -0.0 exists where tiles are tracked)
+  // CLAMP (round 4; wdpm_stencil.h::eighth_clamped): one instruction less per neighbour step, exact while no flow of the step
+  // exceeds 1 m.  A flow is at most (the centre's depth + half an ulp of its elevation) / 8, a cell receives in at most eight
+  // of an iteration's nine passes (it is the centre of the ninth), and within one pass in at most one block: if every depth of
+  // the window was <= M when it was loaded, every depth the window holds during the iteration is <= M (9/8)^8 + 8 ulp < 2.566 M + 8 ulp.
+  // With M < 3.000002 m (the high words of the nine values a step loads, compared as integers: a negative or NaN depth counts as
+  // deep) and elevations below 2^30 m in magnitude (the host's part: `no_clamp`) that is < 7.7 m.  The seven rows of a step's
+  // window were loaded by this step and the two before it: bits 0..2 of `deep`; bit 3 = no_clamp.  A step with any of them set
+  // runs the unclamped stages - same results, the round-3 instruction count.  Wave-uniform: one scalar branch per step.
+  int deep = (!SZ_SAFE && !no_clamp) ? 0 : 8;
   double md_max = 0.0;                  // MD: this lane's max |w - oldw| over the cells of its output block (WDPMCL.c:1239-1254)
   const int colb = c0 + 3 * lane;
   // store side: after the LDS transpose, store instruction k = 0,1,2 writes the strip-relative
@@ -601,6 +614,15 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
           }
         }
       }
+      if constexpr (!SZ_SAFE) {
+        auto hi = [](const double v) { return (unsigned)__double2hiint(v); };
+        auto max3 = [](const unsigned a, const unsigned b, const unsigned c) { const unsigned m = a > b ? a : b; return m > c ? m : c; };
+        unsigned hm = max3(hi(W[4][0]), hi(W[4][1]), hi(W[4][2]));
+        hm = max3(hm, hi(W[5][0]), hi(W[5][1]));
+        hm = max3(hm, hi(W[5][2]), hi(W[6][0]));
+        hm = max3(hm, hi(W[6][1]), hi(W[6][2]));
+        deep = (deep & 8) | ((deep & 3) << 1) | (__ballot(hm > 0x40080000u) != 0 ? 1 : 0);   // 0x40080000'00000000 = 3.0
+      }
       // always issued (the last trips re-read clamped / following rows and drop them)
       prefetch(P, A + 3 * (n + 1));
       // the rows the previous step staged in LDS go out now, behind the new loads and ahead of a
@@ -609,7 +631,8 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
 
       const int rbase = A + 3 * n - 4;                 // slab row of window slot 0
 #ifndef WDPM_ABLATE_COMPUTE                            /* timing experiments only: memory pattern alone */
-      three_stages<MODULE, SZ_SAFE, NSTAGES, (PLAIN ? 1 : 0) | (PRIO && !SZ_SAFE && WDPM_XSEL ? 2 : 0)>(W, D, rbase, g.dr, cdr, ds);
+      if (SZ_SAFE || deep) three_stages<MODULE, SZ_SAFE, NSTAGES, (PLAIN ? 1 : 0)>(W, D, rbase, g.dr, cdr, ds);
+      else three_stages<MODULE, SZ_SAFE, NSTAGES, (PLAIN ? 1 : 0) | 2>(W, D, rbase, g.dr, cdr, ds);
 #else
 #pragma unroll
       for (int j = 0; j < 3; j++) W[0][j] += D[0][j] + D[1][j] + D[2][j];   // keep the dem loads alive
@@ -755,8 +778,9 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
 // ---------------------------------------------------------------------------------------------
 /* NB independent 3x3 blocks of one colour pass, advanced in lockstep (non-outlet form; block b is
  * w[b][row][col] with the centre at [1][1], neighbours in row-major order) */
-template <int MODULE, int NB, bool PLAIN = false>
+template <int MODULE, int NB, int FLAGS = 0>   /* FLAGS as block_update's: bit 0 PLAIN, bit 1 CLAMP */
 __device__ __forceinline__ void blocks_lockstep(double (&w)[NB][3][3], const double (&d)[NB][3][3]) {
+  constexpr bool PLAIN = (FLAGS & 1) != 0, CL = (FLAGS & 2) != 0;
   double wc[NB], dce[NB];
   bool gate[NB];
 #pragma unroll
@@ -771,8 +795,8 @@ __device__ __forceinline__ void blocks_lockstep(double (&w)[NB][3][3], const dou
     const int r = 1 + nb_dr(k), c = 1 + nb_dc(k);
 #pragma unroll
     for (int b = 0; b < NB; b++) {
-      if (MODULE == 2) flow_drain_nz(dce[b], wc[b], d[b][r][c], w[b][r][c]);
-      else flow_add_nz(dce[b], wc[b], d[b][r][c], w[b][r][c]);
+      if (MODULE == 2) flow_drain_nz<CL>(dce[b], wc[b], d[b][r][c], w[b][r][c]);
+      else flow_add_nz<CL>(dce[b], wc[b], d[b][r][c], w[b][r][c]);
     }
   }
 #pragma unroll
@@ -781,7 +805,7 @@ __device__ __forceinline__ void blocks_lockstep(double (&w)[NB][3][3], const dou
 
 /* one row alignment (three column alignments oj = 1,2,3) on the NB row blocks at window slots
  * S0 + 3b .. S0 + 3b + 2 of a window of NR rows; the lockstep twin of stage_impl */
-template <int MODULE, int NB, int S0, int NR, bool PLAIN = false>
+template <int MODULE, int NB, int S0, int NR, int FLAGS = 0>
 __device__ __forceinline__ void stage_lockstep(double (&W)[NR][3], const double (&D)[NR][3]) {
   double w[NB][3][3], d[NB][3][3];
   double n0[NB][3], n1[NB][3], e0[NB][3], e1[NB][3];      // columns 0 and 1 of the next lane: water, elevation
@@ -792,7 +816,7 @@ __device__ __forceinline__ void stage_lockstep(double (&W)[NR][3], const double 
     for (int r = 0; r < 3; r++)
 #pragma unroll
       for (int c = 0; c < 3; c++) { w[b][r][c] = W[S0 + 3 * b + r][c]; d[b][r][c] = D[S0 + 3 * b + r][c]; }
-  blocks_lockstep<MODULE, NB, PLAIN>(w, d);
+  blocks_lockstep<MODULE, NB, FLAGS>(w, d);
   // oj = 2: own columns 1,2 + column 0 of the next lane
 #pragma unroll
   for (int b = 0; b < NB; b++)
@@ -804,7 +828,7 @@ __device__ __forceinline__ void stage_lockstep(double (&W)[NR][3], const double 
       w[b][r][0] = w[b][r][1]; w[b][r][1] = w[b][r][2]; w[b][r][2] = n0[b][r];
       d[b][r][0] = d[b][r][1]; d[b][r][1] = d[b][r][2]; d[b][r][2] = e0[b][r];
     }
-  blocks_lockstep<MODULE, NB, PLAIN>(w, d);
+  blocks_lockstep<MODULE, NB, FLAGS>(w, d);
   // oj = 3: own column 2 + columns 0,1 of the next lane
 #pragma unroll
   for (int b = 0; b < NB; b++)
@@ -815,7 +839,7 @@ __device__ __forceinline__ void stage_lockstep(double (&W)[NR][3], const double 
       w[b][r][0] = w[b][r][1]; w[b][r][1] = w[b][r][2]; w[b][r][2] = n1[b][r];
       d[b][r][0] = d[b][r][1]; d[b][r][1] = d[b][r][2]; d[b][r][2] = e1[b][r];
     }
-  blocks_lockstep<MODULE, NB, PLAIN>(w, d);
+  blocks_lockstep<MODULE, NB, FLAGS>(w, d);
   // own column 2 back into the window; the borrowed columns back to lane+1 (lane 0 keeps its own)
 #pragma unroll
   for (int b = 0; b < NB; b++)
@@ -1016,9 +1040,12 @@ tri_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout, 
     }
   }
   if (!outlet_here) {
-    stage_lockstep<MODULE, K + 2, 0, NR, PLAIN>(W, D);   // oi = 1 on rows 0-2, 3-5, 6-8 (, 9-11)
-    stage_lockstep<MODULE, K + 1, 1, NR, PLAIN>(W, D);   // oi = 2 on rows 1-3, 4-6 (, 7-9)
-    stage_lockstep<MODULE, K, 2, NR, PLAIN>(W, D);       // oi = 3 on rows 2-4 (, 5-7)
+    // (no clamped neighbour step here - see `deep` in the marching kernel: this kernel sits at 256 VGPRs, and a second copy of
+    // the stages behind a test of the window's depths made five of its instantiations spill, 8 - 164 bytes, round 4)
+    constexpr int F = PLAIN ? 1 : 0;
+    stage_lockstep<MODULE, K + 2, 0, NR, F>(W, D);   // oi = 1 on rows 0-2, 3-5, 6-8 (, 9-11)
+    stage_lockstep<MODULE, K + 1, 1, NR, F>(W, D);   // oi = 2 on rows 1-3, 4-6 (, 7-9)
+    stage_lockstep<MODULE, K, 2, NR, F>(W, D);       // oi = 3 on rows 2-4 (, 5-7)
   }
 
   // rows or_lo .. or_hi, columns oc_lo .. oc_hi (slots 0 and 1 only for the raster's first rows)
@@ -1191,14 +1218,30 @@ relay_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
   __shared__ double xch[2][NW][3 * kLanes];
   __shared__ double xdem[2][LDSDEM ? NW : 1][LDSDEM ? 3 * kLanes : 1];   // elevations of a wave's first two rows, for the wave above
   __shared__ double td_sh[3];
+  __shared__ int deep_sh[NW];
+  // The clamped neighbour step where the depths are shallow enough for it to be exact (see `deep` in the marching kernel: the same
+  // bound).  A wave tests the three rows it loaded: enough for the first alignment, which stays inside them; the rows it takes
+  // over afterwards have been through other waves' blocks, so from the first barrier on the workgroup's OR decides.  Wave-uniform.
+  bool deep = (store_plain & 4) != 0;              // the host's part: elevations too large (WDPM_LAUNCH_CLAMP_OK not given)
+  {
+    unsigned hm = 0;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) { const unsigned h = (unsigned)__double2hiint(W[i][j]); hm = h > hm ? h : hm; }
+    deep = deep || __ballot(hm > 0x40080000u) != 0;
+    if (lane == 0) deep_sh[wave] = deep ? 1 : 0;
+  }
   // one row alignment on this wave's block at slots S0 .. S0+2 (st = S0): the outlet's block takes block_update's outlet form
 #define WDPM_RELAY_STAGE(S0)                                                                               \
   do {                                                                                                     \
     if (MODULE == 2 && wo[S0] == wave) {                                                                   \
       stage_impl<2, false, S0, true>(W, D, R0 + S0, g.dr, cdr, ds);                                        \
       if (lane == 0) td_sh[S0] = ds.td;                                                                    \
+    } else if (deep) {                                                                                     \
+      stage_lockstep<MODULE, 1, S0, 7, PLAIN ? 1 : 0>(W, D);                                               \
     } else {                                                                                               \
-      stage_lockstep<MODULE, 1, S0, 7, PLAIN>(W, D);                                                       \
+      stage_lockstep<MODULE, 1, S0, 7, (PLAIN ? 1 : 0) | 2>(W, D);                                         \
     }                                                                                                      \
   } while (0)
   // rprio (launches of a few rounds of workgroups: the host decides): a workgroup's issue priority falls from stage to stage, so that
@@ -1220,6 +1263,8 @@ relay_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
   }
   __syncthreads();
   WDPM_RSTAMP(3);
+#pragma unroll
+  for (int w = 0; w < NW; w++) deep = deep || deep_sh[w] != 0;
   if (MODULE == 2 && wo[0] >= 0) ds.td = td_sh[0];
   if (wave < NW - 1) {
 #pragma unroll
@@ -1322,7 +1367,7 @@ static int resident_waves() {
     blocks = 2;
   // never more than the kernel was built for: the chunk heights and every threshold of the dispatch were measured at that
   // occupancy, and the register count an instantiation ends up with may allow more from one compiler run to the next
-  constexpr int built_for = (MODULE != 2 && DEM32 && !SZ_SAFE) ? WDPM_FUSED_CODES_WAVES : WDPM_FUSED_MIN_WAVES;
+  constexpr int built_for = fused_built_for<MODULE, SZ_SAFE, DEM32, false>();
   if (blocks > built_for) blocks = built_for;
   cached.store(cus * blocks * 4, std::memory_order_relaxed);
   return cus * blocks * 4;
@@ -1398,7 +1443,7 @@ static hipError_t dpp_selfcheck(hipStream_t s) {
 hipError_t wdpm_launch_small_rows(int module, const double *w_in, double *w_out, const double *dem, const DemCode &code,
                                   const SlabGeom &g, int A0, int out_last, int chunk_rows, int signed_zero_safe, bool flush,
                                   double thres, int drain_owed, double *totaldrain, hipStream_t s, TilePlan *tiles,
-                                  const MaxDiffArgs *md, bool fold_md, bool plain, bool *taken)
+                                  const MaxDiffArgs *md, bool fold_md, bool plain, int no_clamp, bool *taken)
 #if !defined(WDPM_TU) || WDPM_TU == 2
 {
   *taken = false;
@@ -1469,6 +1514,7 @@ hipError_t wdpm_launch_small_rows(int module, const double *w_in, double *w_out,
         static std::atomic<int> env_rprio{-1};
         if (env_rprio < 0) { const char *t = getenv("WDPM_RELAY_PRIO"); env_rprio = t ? atoi(t) : 1; }
         if (env_rprio == 2 || (env_rprio == 1 && nwg > cus && (tall ? r8 : r4) <= 4)) relay_plain |= 2;
+        if (no_clamp) relay_plain |= 4;        // bit 2: the clamped neighbour step is not exact on this DEM (see the kernel)
 #define WDPM_RELAY_LAUNCH(...) hipLaunchKernelGGL((relay_iteration_kernel<__VA_ARGS__>), rgrid, rblock, 0, s, w_in, w_out, dem, g, nstr, (int)nwg, A0, out_last, thres, totaldrain, module == 2 ? drain_owed : 0, code, relay_plain)
 #define WDPM_RELAY_PICK(NW)                                                                                        \
         do {                                                                                                       \
@@ -1533,7 +1579,8 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
    * triangle kernel (+3 % at 482^2).  The marching add / subtract kernel keeps its gate: 35 of 1001 instructions per step
    * less changed nothing at 16384^2 and 8192^2 and cost 1 % at 4096^2 (profiles/r03/plain_water_ab.txt; DESIGN.md §4.1: that
    * launch is bound by the memory system and by instruction issue alike). */
-  const bool plain = plain_water && !signed_zero_safe && !flush && !(md && md->old);
+  const bool plain = (plain_water & WDPM_LAUNCH_PLAIN) && !signed_zero_safe && !flush && !(md && md->old);
+  const int no_clamp = (plain_water & WDPM_LAUNCH_CLAMP_OK) ? 0 : 1;     /* see `deep` in the marching kernel */
   const bool fold_md = md && md->old && module != 2 && !signed_zero_safe;
   if (md && md->old && !fold_md) return hipErrorInvalidValue;     /* the caller asks only where a folding variant exists */
   hipError_t e = dpp_selfcheck(s);
@@ -1544,7 +1591,7 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
   {
     bool taken = false;
     e = wdpm_launch_small_rows(module, w_in, w_out, dem, code, g, A0, out_last, chunk_rows, signed_zero_safe, flush != nullptr, thres,
-                               drain_owed, totaldrain, s, tiles, md, fold_md, plain, &taken);
+                               drain_owed, totaldrain, s, tiles, md, fold_md, plain, no_clamp, &taken);
     if (taken || e != hipSuccess) return e;
   }
   int nstrips = 1;
@@ -1622,10 +1669,10 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
   // Two workgroups per CU, whatever the register allocator ends up with: the instantiations that stream DEM codes come out at
   // 166 VGPRs with the priority loop (238 without), which would let the dispatcher stack three workgroups on some CUs and one
   // on others.  36 KiB of unused dynamic LDS beside the 18 KiB of staging: two fit a CU's 160 KiB, three do not.
-  const int built_for = (module != 2 && dem32) ? WDPM_FUSED_CODES_WAVES : WDPM_FUSED_MIN_WAVES;
+  const int built_for = (module == 2 && !fast) ? 1 : (module != 2 && dem32) ? WDPM_FUSED_CODES_WAVES : WDPM_FUSED_MIN_WAVES;
   const unsigned lds_pad = env_pad.load(std::memory_order_relaxed) >= 0 ? (unsigned)env_pad.load(std::memory_order_relaxed)
                                                                         : (built_for <= 2 ? 36864u : 0u);
-#define WDPM_LAUNCH(...) hipLaunchKernelGGL((fused_iteration_kernel<__VA_ARGS__>), grid, block, lds_pad, s, w_in, w_out, dem, code, g, nstrips, nitems, H, A0, out_last, totaldrain, thres, module == 2 ? drain_owed : 0, tf, mda, store_plain)
+#define WDPM_LAUNCH(...) hipLaunchKernelGGL((fused_iteration_kernel<__VA_ARGS__>), grid, block, lds_pad, s, w_in, w_out, dem, code, g, nstrips, nitems, H, A0, out_last, totaldrain, thres, module == 2 ? drain_owed : 0, tf, mda, store_plain, no_clamp)
 #define WDPM_LAUNCH_FM(M, Z, D32) do { if (fold_md) { if (flush) WDPM_LAUNCH(M, Z, D32, true, true); else WDPM_LAUNCH(M, Z, D32, false, true); } \
                                        else { if (flush) WDPM_LAUNCH(M, Z, D32, true, false); else WDPM_LAUNCH(M, Z, D32, false, false); } } while (0)
   // tall chunks: the instantiations whose waves lower their issue priority as they advance (see the marching loop)

@@ -31,7 +31,8 @@ struct DemCode {
   int force;         /* use the codes on launches of any size (tests); normally only where they pay */
 };
 
-/* smallest valid (finite) dem value, as an order-preserving uint64 key in *key (all ones: none) */
+/* smallest valid (finite) dem value, as an order-preserving uint64 key in key[0] (all ones: none), and the bit image of the
+ * largest |dem| over the valid cells in key[1] (0: none) */
 hipError_t wdpm_launch_dem_min(const double *dem, size_t cells, unsigned long long *key, hipStream_t s);
 double wdpm_dem_key_to_double(unsigned long long key);
 /* q[i] = code of dem[i]; *bad |= 1 if any cell does not decode to exactly dem[i] */
@@ -106,8 +107,12 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
                                   int signed_zero_safe, const double *flush, int drain_owed, double *totaldrain,
                                   hipStream_t s, TilePlan *tiles = nullptr, const MaxDiffArgs *md = nullptr,
                                   int leave_cus = 0, int plain_water = 0);
-/* plain_water: the caller knows (wdpm_launch_scan_water, and nothing written since that could change it) that every cell of
- * w_in that may not give water holds +0.0: launches that have such a variant then run without the centre gate */
+/* plain_water, bit 0 (WDPM_LAUNCH_PLAIN): the caller knows (wdpm_launch_scan_water, and nothing written since that could change
+ * it) that every cell of w_in that may not give water holds +0.0: launches that have such a variant then run without the centre gate.
+ * bit 1 (WDPM_LAUNCH_CLAMP_OK): every valid elevation is below 2^30 m in magnitude (wdpm_launch_dem_min), so that half an ulp of an
+ * elevation is nothing against a depth: the kernels may take a flow's `max(x / 8, -0.0)` as one clamped instruction wherever
+ * the depths they hold are shallow enough for it to be exact (wdpm_stencil.h::eighth_clamped, `deep` in wdpm_fused.hip). */
+enum { WDPM_LAUNCH_PLAIN = 1, WDPM_LAUNCH_CLAMP_OK = 2 };
 /* leave_cus: size the launch as if the chip had that many compute units fewer - the interior launch of an overlapped
  * iteration leaves room for the RCCL send/recv kernels queued beside it (a launch otherwise fills every slot for its
  * whole duration, and the transfer would start only when the first waves retire) */

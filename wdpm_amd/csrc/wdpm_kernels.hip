@@ -172,24 +172,28 @@ double wdpm_dem_key_to_double(unsigned long long key) {
 __global__ void __launch_bounds__(256)
 dem_min_kernel(const double *__restrict__ dem, size_t n, unsigned long long *key) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  unsigned long long m = ~0ull;
+  unsigned long long m = ~0ull, a = 0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const double v = dem[i];
     if (cell_valid(v)) {
       const unsigned long long kx = ordered_key(v);
       m = kx < m ? kx : m;
+      const unsigned long long ab = (unsigned long long)__double_as_longlong(v) & 0x7fffffffffffffffull;   // |v|: monotone as an integer
+      a = ab > a ? ab : a;
     }
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
-    const unsigned long long o = __shfl_xor(m, off, 64);
+    const unsigned long long o = __shfl_xor(m, off, 64), oa = __shfl_xor(a, off, 64);
     m = o < m ? o : m;
+    a = oa > a ? oa : a;
   }
-  if ((threadIdx.x & 63) == 0 && m != ~0ull) atomicMin(key, m);
+  if ((threadIdx.x & 63) == 0 && m != ~0ull) { atomicMin(key, m); atomicMax(key + 1, a); }
 }
 
 hipError_t wdpm_launch_dem_min(const double *dem, size_t cells, unsigned long long *key, hipStream_t s) {
   hipError_t e = hipMemsetAsync(key, 0xff, sizeof(unsigned long long), s);
+  if (e == hipSuccess) e = hipMemsetAsync(key + 1, 0, sizeof(unsigned long long), s);
   if (e != hipSuccess || cells == 0) return e;
   size_t blocks = (cells + 255) / 256;
   if (blocks > 2048) blocks = 2048;

@@ -92,28 +92,26 @@ __device__ __forceinline__ void flow_add(const double dem_c, double &w_c, const 
  *     i.e. w_c >= ulp(a)/2 (or w_c dominates), hence ht <= 2 w_c (1 + 2^-53) < 8 w_c.
  * tests/test_stencil_forms.py checks (a),(b) on ~10^8 adversarial operand tuples against the
  * reference form, and the GPU parity tests run this variant on every golden vector. */
-/* XSEL: the 64-bit select `c ? a : b` as v_cmpx (the compare writes EXEC) + ONE v_mov_b64 under that mask, instead of a compare
- * into VCC and two v_cndmask_b32: one VALU instruction less per neighbour step; EXEC is saved and restored on the scalar unit
- * inside the statement.  Same value, lane for lane.  Only for kernels bound by VALU issue with a second wave to cover the
- * EXEC write -> VALU read latency (the marching kernel's PRIO instantiations: wdpm_fused.hip); a lone wave loses by it
- * (round 2: -10 % on basin5-sized rasters).  gfx9 hazard "VALU writes EXEC -> DPP: 5 wait states": the compiler schedules the
- * windows' DPP moves 2-3 instructions behind the statement, so it carries an s_nop 2, and tools/check_asm_loads.py counts the
- * wait states in the generated ISA.  With the s_nop: add 16384^2 -0.7 %, drain 8192^2 -2.7 % (profiles/r03/xsel_ab.txt):
- * compiled only with -DWDPM_XSEL=1. */
-__device__ __forceinline__ double select_gt_exec(const double c0, const double c1, const double if_gt, const double otherwise) {
-  double x = otherwise;
-  unsigned long long saved;
-  asm("s_mov_b64 %1, exec\n\tv_cmpx_gt_f64_e32 %2, %3\n\tv_mov_b64_e32 %0, %4\n\ts_mov_b64 exec, %1\n\ts_nop 2"
-      : "+v"(x), "=&s"(saved) : "v"(c0), "v"(c1), "v"(if_gt) : "vcc");
-  return x;
+/* CLAMP (round 4): `max(x / 8, -0.0)` as ONE instruction.  The VOP3 clamp bit on an fp64 result clamps to [0, 1]
+ * after rounding, NaN -> +0.0 (DX10_CLAMP, the HSA default), subnormal quotients kept: tools/clamp_probe.hip ran it against
+ * v_ldexp_f64 + v_max_f64 on 4 * 10^6 adversarial operands on the chip - equal for every x <= 8 up to the sign of a zero result
+ * (+0.0 here where the two-instruction form gives -0.0; `w + (+-0)` and `w - |+-0|` return w either way for every w that is not
+ * -0.0, which the _nz forms exclude).  For x > 8 the result is 1.0 instead of x / 8, so a caller may use it only where no flow
+ * of a neighbour step can exceed 1 m - the kernels establish that per wave and step from the depths they hold
+ * (wdpm_fused.hip: `deep`): a flow is at most (centre depth + half an ulp of its elevation) / 8, and a depth grows by at most
+ * that in each of the eight passes of an iteration in which its cell receives. */
+__device__ __forceinline__ double eighth_clamped(const double x) {
+  double r;
+  asm("v_ldexp_f64 %0, %1, -3 clamp" : "=v"(r) : "v"(x));
+  return r;
 }
 
-template <bool XSEL = false>
+template <bool CLAMP = false>
 __device__ __forceinline__ void flow_add_nz(const double dem_c, double &w_c, const double dem_n, double &w_n) {
   const double en = dem_n + w_n;                 // :1946
   const double ht = (dem_c + w_c) - en;          // :1945-1946
-  const double x = XSEL ? select_gt_exec(dem_c, en, w_c, ht) : ((dem_c > en) ? w_c : ht);      // :1948-1955
-  const double f = vmax_f64(x * 0.125, -0.0);    // :1947 + :1949/:1955 (+ :1957, a no-op)
+  const double x = (dem_c > en) ? w_c : ht;      // :1948-1955
+  const double f = CLAMP ? eighth_clamped(x) : vmax_f64(x * 0.125, -0.0);    // :1947 + :1949/:1955 (+ :1957, a no-op)
   w_c = w_c - __builtin_fabs(f);                 // :1958
   w_n = w_n + f;                                 // :1959
 }
@@ -158,7 +156,7 @@ __device__ __forceinline__ void flow_drain(const double dem_c, double &w_c, cons
  *   about the sign of a difference near zero: the reference tests ht, so must we), f = +-0, and
  *   both updates return their inputs.
  * tests/test_stencil_forms.py checks this against the reference form on adversarial operands. */
-template <bool XSEL = false>
+template <bool CLAMP = false>
 __device__ __forceinline__ void flow_drain_nz(const double dem_c, double &w_c, const double dem_n, double &w_n) {
   const double nwe = dem_n + w_n;                               // :1978
   const double ht = (dem_c + w_c) - nwe;                        // :1977,1988
@@ -168,8 +166,8 @@ __device__ __forceinline__ void flow_drain_nz(const double dem_c, double &w_c, c
   // ternary the compiler cannot speculate it and builds a divergent branch (s_and_saveexec /
   // s_cbranch_execz) around EVERY neighbour step - 72 branches per window step, no scheduling across them
   const double m = vmin_f64(s, big);
-  const double x = XSEL ? select_gt_exec(dem_c, nwe, w_c, m) : ((dem_c > nwe) ? w_c : m);   // :1990-1996
-  double f = vmax_f64(x * 0.125, -0.0);                         // :1998 max(flow, 0.0); NaN -> -0.0
+  const double x = (dem_c > nwe) ? w_c : m;                     // :1990-1996
+  double f = CLAMP ? eighth_clamped(x) : vmax_f64(x * 0.125, -0.0);   // :1998 max(flow, 0.0); NaN -> +-0
   f = vmin_f64(f, w_c);                                         // :1998 min(.., w_c)
   w_c = w_c - __builtin_fabs(f);                                // :1999
   w_n = w_n + f;                                                // :2000
