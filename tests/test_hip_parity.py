@@ -733,7 +733,7 @@ def test_guard_bands_notice_a_stray_write(hip):
         assert c.get_option(wdpm_amd.capi.OPT_GUARD_BAD) == 0
         p = c.water_ptr()
         assert rt.hipMemset(p - 3, 0, 3) == 0
-        assert rt.hipMemset(p + ((R + 2) * (Cc + 2) + 64) * 8, 0, 2) == 0
+        assert rt.hipMemset(p + ((R + 2) * (Cc + 2) + 192) * 8, 0, 2) == 0      # 192 doubles: the dump area (wdpm_create)
         assert rt.hipDeviceSynchronize() == 0
         assert c.get_option(wdpm_amd.capi.OPT_GUARD_BAD) == 5
     finally:

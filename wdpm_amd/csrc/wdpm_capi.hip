@@ -295,10 +295,10 @@ int wdpm_create(wdpm_ctx **out, const wdpm_params *p) {
   if (e == hipSuccess) e = hipEventCreateWithFlags(&x->ev_fork, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&x->ev_join, hipEventDisableTiming);
   if (e == hipSuccess) e = guarded_malloc(x, (void **)&x->d_dem, bytes);
-  /* + 64 doubles behind each water raster: the fused kernel's dump area for masked-out stores */
-  if (e == hipSuccess) e = guarded_malloc(x, (void **)&x->d_w[0], bytes + 64 * sizeof(double));
-  if (e == hipSuccess) e = guarded_malloc(x, (void **)&x->d_w[1], bytes + 64 * sizeof(double));
-  if (e == hipSuccess) e = guarded_malloc(x, (void **)&x->d_w[2], bytes + 64 * sizeof(double));
+  /* + 192 doubles behind each water raster: the fused kernel's dump area for masked-out stores (a strip's width) */
+  if (e == hipSuccess) e = guarded_malloc(x, (void **)&x->d_w[0], bytes + 192 * sizeof(double));
+  if (e == hipSuccess) e = guarded_malloc(x, (void **)&x->d_w[1], bytes + 192 * sizeof(double));
+  if (e == hipSuccess) e = guarded_malloc(x, (void **)&x->d_w[2], bytes + 192 * sizeof(double));
   if (e == hipSuccess) e = guarded_malloc(x, (void **)&x->d_dem32, x->cells * sizeof(int) + 64);
   if (e == hipSuccess) e = hipMalloc(&x->d_scal, 2 * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&x->d_bits, 2 * sizeof(unsigned long long));

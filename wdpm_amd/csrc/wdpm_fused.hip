@@ -305,13 +305,6 @@ static __device__ unsigned long long g_wave_times[4 * 8192];   /* one per transl
 #ifndef WDPM_FUSED_MIN_WAVES
 #define WDPM_FUSED_MIN_WAVES 2   /* waves per SIMD the register allocator must leave room for */
 #endif
-#ifndef WDPM_PRIO_PEEL
-#define WDPM_PRIO_PEEL 1         /* add / subtract PRIO instantiations leave the dead stages of a chunk's first two steps out, as drain does */
-#endif
-#ifndef WDPM_PRIO_OLD            /* PRIO instantiations: where a wave's issue priority drops a level, in 64ths of its chunk - see the marching loop */
-#define WDPM_PRIO_OLD 18, 45, 56
-#define WDPM_PRIO_YOUNG 37, 49, 62
-#endif
 #ifndef WDPM_FUSED_CODES_WAVES
 #define WDPM_FUSED_CODES_WAVES 2 /* the same for the add / subtract instances that stream the DEM as codes */
 #endif
@@ -333,13 +326,13 @@ constexpr int fused_built_for() {
   return (MODULE == 2 && SZ_SAFE) ? 1 : (MODULE != 2 && DEM32 && !MD && !SZ_SAFE) ? WDPM_FUSED_CODES_WAVES : WDPM_FUSED_MIN_WAVES;
 }
 
-template <int MODULE, bool SZ_SAFE, bool DEM32, bool FLUSH = false, bool MD = false, bool PLAIN = false, bool PRIO = false>
-__global__ void __launch_bounds__(256, (fused_built_for<MODULE, SZ_SAFE, DEM32, MD>()))
+template <int MODULE, bool SZ_SAFE, bool DEM32, bool FLUSH = false, bool MD = false, bool PLAIN = false>
+__global__ void __launch_bounds__((fused_built_for<MODULE, SZ_SAFE, DEM32, MD>() >= 2 ? 512 : 256), (fused_built_for<MODULE, SZ_SAFE, DEM32, MD>()))
 fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout,
                        const double *__restrict__ dem, const DemCode code, const SlabGeom g, const int nstrips,
                        const int nitems, const int H, const int A0, const int out_last,
                        double *__restrict__ totaldrain, const double thres, const int drain_owed,
-                       const TileFlags tf, const MaxDiffArgs md, const int store_plain, const int no_clamp) {
+                       const TileFlags tf, const MaxDiffArgs md, const int prio, const int no_clamp) {
   const int lane = threadIdx.x & 63;
   // Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2; placement is only a
   // speed matter, never correctness): give each XCD a contiguous run of work items so that the
@@ -353,7 +346,9 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
   // the wave number is the same in all 64 lanes: say so, and everything derived from it (strip,
   // chunk, row bases, loop bounds) lives in SGPRs and is computed on the scalar unit
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int item = vb * 4 + wave;
+  // A workgroup is eight waves where the launch puts two waves on every SIMD (one workgroup per CU: the two waves of a SIMD can
+  // then see each other's progress in LDS - see `prio` in the marching loop), four where it leaves half of the slots empty.
+  const int item = vb * (int)(blockDim.x >> 6) + wave;
   if (item >= nitems) return;                       // wave-uniform
 #ifdef WDPM_WAVE_TIMES
   const unsigned long long wt0 = wall_clock64();
@@ -416,14 +411,20 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
   // lane, so every store is unconditional (fixed instruction count) and nothing is written twice
   // with different data.
   int scol[3];
+  unsigned soff[3];                     // the same as byte offsets: a store's address is a wave-uniform row base (SGPRs) + this
   {
     const int lo = oc_lo - c0;
     const int hi = (oc_hi < g.ncp - 1 ? oc_hi : g.ncp - 1) - c0;
 #pragma unroll
-    for (int k = 0; k < 3; k++) scol[k] = lo + 64 * k + lane < hi ? lo + 64 * k + lane : hi;
+    for (int k = 0; k < 3; k++) { scol[k] = lo + 64 * k + lane < hi ? lo + 64 * k + lane : hi; soff[k] = 8u * (unsigned)scol[k]; }
   }
-  __shared__ double stage_all[4][3 * kStripIn];          // 4.5 KiB per wave, private to the wave
+  __shared__ double stage_all[8][3 * kStripIn];          // 4.5 KiB per wave, private to the wave
+  __shared__ int progress_all[8];                        // see `prio` in the marching loop
   double *const stage_lds = stage_all[wave];
+  const unsigned hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4);                   // HW_ID: wave slot [3:0], SIMD [5:4]
+  const int my_word = (int)(((hw_id >> 4) & 3) * 2 + (hw_id & 1));
+  volatile int *const my_progress = progress_all + my_word;
+  volatile int *const partner_progress = progress_all + (my_word ^ 1);
   bool cdr[5];
 #pragma unroll
   for (int j = 0; j < 5; j++) cdr[j] = MODULE == 2 && colb + j == g.dc;
@@ -473,7 +474,10 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
   // number of loads and stores on every trip, so the compiler can wait with exact vmcnt counts
   // (with conditional memory operations it falls back to vmcnt(0) at the top of each step, which
   // exposes the full latency of the stores just issued — measured 27 % of the kernel).
-  double *const dump = wout + (size_t)g.rows * pitch + lane;   // 64 doubles, allocated by wdpm_create
+  // (192 doubles behind the raster, allocated by wdpm_create: a dumped row goes there at the same lane offsets as a stored one, so
+  // that every store is "uniform base + lane offset" - the saddr form, no 64-bit address arithmetic on the vector unit: nine
+  // v_lshl_add_u64 per step less, round 4)
+  char *const dump = reinterpret_cast<char *>(wout + (size_t)g.rows * pitch);
 
   // The marching loop, instantiated for interior (EDGE = false) and edge waves.
   auto march = [&](auto edge_tag) {
@@ -565,23 +569,27 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
         const int r = rb + i;
         const bool row_ok = r >= or_lo && r <= or_hi;             // wave-uniform
         // rows outside the chunk's output range (first / last trips only) go to the dump area
-        double *const orow = wout + (size_t)(row_ok ? r : 0) * pitch + c0;
-        // store_plain (wave-uniform; round 3): ordinary stores where the raster the next iteration reads back fits the Infinity
-        // Cache in good part - add 3600^2 79.8 -> 76.2 us, 4096^2 96.3 -> 91.6, 6000^2 192.9 -> 181.0, 8192^2 -2 %, 16384^2 -0.9 %;
-        // below that and for drain non-temporal stores are ahead (2400^2 42.8 against 43.6; profiles/r03/plain_stores_ab.txt)
-        if (store_plain) {
+        char *const orow = row_ok ? reinterpret_cast<char *>(wout + (size_t)r * pitch + c0) : dump;   // wave-uniform
+        // Stores as inline asm, saddr form: a wave-uniform row base in SGPRs + the lane's byte offset, no address arithmetic on
+        // the vector unit.  Ordinary stores, not non-temporal ones (round 4).  Rounds 1 - 3 believed they were choosing between
+        // the two by size: left to the compiler, the two arms of that branch (the same store with and without !nontemporal)
+        // had been merged into ONE plain store with a 64-bit VALU address - round 3's final ISA has no `nt` store in this
+        // kernel at all.  With real `nt` stores measured against plain ones (profiles/r04/stores_shapes_ab.txt): add 4096^2
+        // 108.0 against 103.1 us, 3000^2 65.9 against 62.9, drain 8192^2 401.6 against 397.8, the 1053-row drain slab 77.7
+        // against 75.2; a tie at 8192^2 add, on the 2116-row add slab and at 16384^2; drain 4096^2 128.9 against 130.3.
 #pragma unroll
-          for (int k = 0; k < 3; k++) *(row_ok ? orow + scol[k] : dump) = staged[i][k];
-        } else {
-#pragma unroll
-          for (int k = 0; k < 3; k++) __builtin_nontemporal_store(staged[i][k], row_ok ? orow + scol[k] : dump);
-        }
+        for (int k = 0; k < 3; k++) asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(soff[k]), "v"(staged[i][k]), "s"(orow) : "memory");
       }
       __builtin_amdgcn_wave_barrier();
     };
 
     auto step = [&](const int n, Prefetched &P, auto nstages_tag) {
       constexpr int NSTAGES = decltype(nstages_tag)::value;
+      int partner_at = 0;
+      if (prio) {                                        // wave-uniform
+        *my_progress = n;                                // every lane the same word
+        partner_at = *partner_progress;                  // read back after the step's arithmetic
+      }
       read_staged();
       // consume the prefetched rows into window slots 4..6; the device DEM already holds +inf for
       // NODATA cells, so only edge waves have anything to mask (outside the slab: dem=+inf, w=0)
@@ -591,7 +599,7 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
         for (int j = 0; j < 3; j++) {
           // FLUSH: the block's threshold flush (WDPMCL.c:1059-1062) applied to the water as it arrives
           W[4 + i][j] = FLUSH && P.NW[i][j] < thres ? 0.0 : P.NW[i][j];
-          if (DEM32) D[4 + i][j] = dem32_decode(EDGE ? P.qe[i][j] : P.qi[i][j], code.k0, code.D, code.rD);
+          if (DEM32) D[4 + i][j] = dem32_decode_nan(EDGE ? P.qe[i][j] : P.qi[i][j], code.k0, code.D, code.rD);
           else D[4 + i][j] = P.ND[i][j];
         }
       if (MODULE == 2 && owed_here && A + 3 * n + 2 >= g.dr - 1 && A + 3 * n <= g.dr + 1) {   // wave-uniform, rare
@@ -664,14 +672,25 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
           }
         }
       }
+      unsigned any_lo = 0, any_hi = 0;
 #pragma unroll
       for (int i = 0; i < 3; i++)
 #pragma unroll
         for (int j = 0; j < 3; j++) {
           stage_lds[i * kStripIn + 3 * lane + j] = W[i][j];
-          nzmask |= __ballot(W[i][j] != 0.0);            // one compare + a scalar OR per value
+          // "is any staged value something other than +0.0?": the OR of the nine bit images (v_or3_b32: nine instructions and one
+          // compare per step, where a compare per value took twenty)
+          any_lo |= (unsigned)__double2loint(W[i][j]);
+          any_hi |= (unsigned)__double2hiint(W[i][j]);
         }
+      nzmask |= __ballot((any_lo | any_hi) != 0);
       __builtin_amdgcn_wave_barrier();
+      if (prio) {
+        const int p = __builtin_amdgcn_readfirstlane(partner_at);
+        if (p > n) __builtin_amdgcn_s_setprio(3);        // the other wave of this SIMD is ahead: this one is served first
+        else if (p < n) __builtin_amdgcn_s_setprio(0);
+        else __builtin_amdgcn_s_setprio(1);
+      }
       // The rows requested at the top of this step must have landed before the compiler may touch
       // their registers (it copies them around the loop back-edge): wait here, where the only
       // younger memory operations are the 9 stores issued right after them.
@@ -685,53 +704,29 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
 
     // The SIMD's arbiter serves the OLDER of its two waves first whenever both have an instruction ready.  Left alone, the older
     // wave of every SIMD gets ~65 % of the issue slots, finishes its chunk at 0.65 of the launch's time, and the younger runs
-    // the last third alone with nobody to hide its latencies behind (tools/wave_times.py, profiles/r03/wave_times.txt: ends
-    // p50 761 us, p90 1149 us of a 1175 us launch; wave-time in flight / (waves x span) = 0.78).  So a wave's priority
-    // (s_setprio, four levels) FALLS as it advances, and the wave behind is served first; equal levels still go to the older
-    // wave (wave slot 0 when a launch starts on an empty chip), so its levels end earlier than the younger's (slot 1) -
-    // boundaries in 64ths of the chunk, from a two-wave model of the arbiter and a sweep on the chip: both waves of a
-    // SIMD now end within 1-2 % of each other (0.955 in flight), 16384^2 add 1.206 -> 1.165 ms, drain 8192^2 0.428 -> 0.412 ms
-    // (profiles/r03/prio_ab.txt).  Chunks of a few steps lose by it (add 4096^2, 18 steps: -4 %; the 1055-row drain slab, 11 steps:
-    // -5 %; add 6000^2, 38 steps: -1 %, 7000^2, 50 steps: +2 %; drain 6000^2, 38 steps: +3 %, 19 steps: 0 ... -1.5 %), and the
-    // loop's shape alone changes the compiler's schedule (166 instead of 238 VGPRs for the DEM-code instances, 1 % slower on short
-    // chunks): PRIO is an instantiation of its own, chosen by the host for launches of tall chunks (wdpm_launch_fused_rows).
-    // Priorities decide who issues, never what is computed.  WDPM_PRIO=0 in the environment: never.
-#define WDPM_MARCH_FROM(N0)                                                                                      \
-    if constexpr (PRIO) {                                                                                         \
-      constexpr int bo[3] = {WDPM_PRIO_OLD}, by[3] = {WDPM_PRIO_YOUNG};                                           \
-      const int slot_odd = __builtin_amdgcn_s_getreg((0 << 11) | 4) & 1;     /* HW_ID.WAVE_ID bit 0 */            \
-      const int b1 = slot_odd ? by[0] : bo[0], b2 = slot_odd ? by[1] : bo[1], b3 = slot_odd ? by[2] : bo[2];      \
-      _Pragma("nounroll") for (int q = 0; q < 4; q++) {                                                           \
-        int f_lo, f_hi;                                                                                           \
-        if (q == 0) { __builtin_amdgcn_s_setprio(3); f_lo = 0; f_hi = b1; }                                       \
-        else if (q == 1) { __builtin_amdgcn_s_setprio(2); f_lo = b1; f_hi = b2; }                                 \
-        else if (q == 2) { __builtin_amdgcn_s_setprio(1); f_lo = b2; f_hi = b3; }                                 \
-        else { __builtin_amdgcn_s_setprio(0); f_lo = b3; f_hi = 64; }                                             \
-        const int n_hi = (N0) + (nsteps - (N0)) * f_hi / 64;                                                      \
-        for (int n = (N0) + (nsteps - (N0)) * f_lo / 64; n < n_hi; n++) step(n, P, std::integral_constant<int, 3>{}); \
-      }                                                                                                           \
-    } else {                                                                                                      \
-      for (int n = (N0); n < nsteps; n++) step(n, P, std::integral_constant<int, 3>{});                          \
-    }
+    // the last third alone with nobody to hide its latencies behind (tools/wave_times.py; 4096^2 in round 4: slot 0 ends at
+    // 55.7 us, slot 1 at 85.2 us of a 90.4 us launch, wave-time in flight / (waves x span) = 0.77).
+    // Round 3 answered with priorities that FALL as a wave advances through its chunk (four levels at fixed fractions, the
+    // fractions different for the two slots, from a two-wave model of the arbiter): 0.96 in flight at 16384^2 (+5.6 %), but nothing
+    // or a loss on chunks of fewer than ~40 steps - 4096^2, every 8-GPU slab - and an instantiation of its own.
+    // Round 4: the two waves TELL each other where they are.  With two waves per SIMD a workgroup is eight waves, one workgroup
+    // per CU, so the two waves of a SIMD share LDS: each step a wave writes its step number to its word (SIMD id x 2 + the low
+    // bit of its wave slot, from HW_ID) and reads the other's; whoever is behind gets priority 3, whoever is ahead 0, level 1
+    // when they are level (the older then leads by a step, and is overtaken).  Two LDS operations and a few scalar
+    // instructions per step, no assumption about chunk heights or about who started first; a partner that has finished, or
+    // never existed, reads as "ahead" or as garbage - either way only who issues first is decided here, never what is computed.
+    // `prio` = 0 (WDPM_PRIO=0, or a launch of four-wave workgroups): no priorities.
     Prefetched P;
     prefetch(P, A);
     WDPM_WAIT_ROWS(0);
-    if constexpr (MODULE == 2 || (PRIO && WDPM_PRIO_PEEL)) {
-      // drain is bound by instruction issue (16 instructions per neighbour step): the dead stages of a chunk's first two
-      // steps are left out (1-3 % at 4096^2, 5 % on the 1055-row slabs of 8 GPUs).  Add / subtract keep them: those
-      // launches are bound by the memory system, the arithmetic of the first steps paces the waves' first requests, and
-      // without it 4096^2 ran 4 % SLOWER (profiles/r03/warmup_stages_ab.txt)
-      step(0, P, std::integral_constant<int, 1>{});      // nsteps >= 3: H >= 3
-      step(1, P, std::integral_constant<int, 2>{});
-      WDPM_MARCH_FROM(2);
-    } else {
-      WDPM_MARCH_FROM(0);
-    }
+    // The dead stages of a chunk's first two steps are left out (see three_stages): 3 of 3 (H/3 + 2) stage executions.
+    step(0, P, std::integral_constant<int, 1>{});      // nsteps >= 3: H >= 3
+    step(1, P, std::integral_constant<int, 2>{});
+    for (int n = 2; n < nsteps; n++) step(n, P, std::integral_constant<int, 3>{});
     read_staged();
     write_staged(A + 3 * (nsteps - 1) - 4);    // the last step's rows
 #undef WDPM_WAIT_ROWS
 #undef WDPM_WAIT_W
-#undef WDPM_MARCH_FROM
   };
   if (edge) march(std::true_type{});
   else march(std::false_type{});
@@ -1151,7 +1146,7 @@ relay_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
     for (int j = 0; j < 3; j++) {
       // DEM32: the elevations as verified-lossless 32-bit codes (wdpm_kernels.h::DemCode): launches of several rounds are bound
       // by the memory system, and four bytes per cell less are worth nine decodes per wave there
-      if (DEM32) D[i][j] = dem32_decode(*reinterpret_cast<const int *>(bq + voff[j] / 2), code.k0, code.D, code.rD);
+      if (DEM32) D[i][j] = dem32_decode_nan(*reinterpret_cast<const int *>(bq + voff[j] / 2), code.k0, code.D, code.rD);
       else D[i][j] = *reinterpret_cast<const double *>(bd + voff[j]);
       W[i][j] = i < 3 ? *reinterpret_cast<const double *>(bw + voff[j]) : 0.0;
     }
@@ -1373,20 +1368,6 @@ static int resident_waves() {
   return cus * blocks * 4;
 }
 
-/* WDPM_PLAIN_ADD=0: the tall-chunk add launches keep the centre gate (A/B) */
-static int env_plain_add() {
-  static std::atomic<int> v{-1};
-  if (v < 0) { const char *e = getenv("WDPM_PLAIN_ADD"); v = e ? atoi(e) : 1; }
-  return v;
-}
-
-/* WDPM_STORES=nt|plain forces the water raster's store policy (A/B); default 0 = by size and module */
-static int env_stores() {
-  static std::atomic<int> v{-1};
-  if (v < 0) { const char *e = getenv("WDPM_STORES"); v = !e ? 0 : (!strcmp(e, "plain") ? 2 : (!strcmp(e, "nt") ? 1 : 0)); }
-  return v;
-}
-
 /* chunk height in rows (multiple of 3): the rows are cut into as many chunks as keep
  * strips x chunks within one resident round; each chunk pays a 6-row warm-up. */
 static int pick_chunk_rows(const int rows, const int nstrips, const int override_rows, const int slots) {
@@ -1509,7 +1490,7 @@ hipError_t wdpm_launch_small_rows(int module, const double *w_in, double *w_out,
                              env_relay == 2);
       if (env_relay && !fold_md && relay_ok) {
         const dim3 rgrid(((unsigned)nwg + 7) / 8 * 8), rblock(tall ? 512 : 256);
-        int relay_plain = env_stores() == 2 || (env_stores() == 0 && module != 2 && tall && r8 >= 6);   // 2000^2 25.8 -> 25.1 us, 3000^2 50.1 -> 46.1
+        int relay_plain = (module != 2 && tall && r8 >= 6) ? 1 : 0;   // 2000^2 25.8 -> 25.1 us, 3000^2 50.1 -> 46.1
         // bit 1: stage priorities, where workgroups share SIMDs and the launch is a few rounds long (see the kernel; WDPM_RELAY_PRIO=0/2: never / always)
         static std::atomic<int> env_rprio{-1};
         if (env_rprio < 0) { const char *t = getenv("WDPM_RELAY_PRIO"); env_rprio = t ? atoi(t) : 1; }
@@ -1604,6 +1585,7 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
   // profiles/r01: 512^2 - 3072^2 slower with codes, 4096^2 and up 5-12 % faster).
   const bool big = (long long)(out_last - A0 + 1) * nstrips >= 36LL * resident_waves<0, false>();
   const bool dem32 = fast && module != 2 && code.q != nullptr && (big || code.force);
+  bool two_per_simd = false;      /* every slot filled: two waves per SIMD, workgroups of eight waves (one per CU) */
   int slots = module == 2 ? (fast ? resident_waves<2, false>() : resident_waves<2, true>())
               : dem32     ? resident_waves<0, false, true>()
               : fast      ? resident_waves<0, false>()
@@ -1613,23 +1595,18 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
     // concurrent DRAM row streams and, on rasters too small to fill the chip, makes the dispatcher
     // double up waves on some SIMDs while others idle.  Filling half of the resident slots measured
     // +4 % at 16384^2, +13 % at 6000^2, x1.9 at 1500^2, x2.3 at 1024^2 (-4 % at 4096^2).
-    // WDPM_FILL_PERCENT overrides (tuning only).
     // The drain variant is different: 16 instructions per neighbour step on one dependent chain per
     // lane leave it latency-bound (59 % VALU issue at one wave per SIMD), and a second wave per SIMD
     // fills the bubbles: +21 % at 8192^2, +30 % at 16384^2 - as long as the chunks stay tall enough
     // for the 6-row warm-up of each not to eat the gain.
-    static std::atomic<int> env_pct{-1};
-    if (env_pct < 0) { const char *e = getenv("WDPM_FILL_PERCENT"); env_pct = e ? atoi(e) : 0; }
     // With the DEM as 32-bit codes the add kernel is in the same position: fewer bytes, nine decodes
     // more per step - one wave per SIMD 1.34 ms per 16384^2 launch (no gain), two waves 1.23 ms.
     // Thresholds from tools/threshold_sweep.sh and tools/slab_sweep.sh (profiles/r01): chunk height at
     // two waves per SIMD >= 36 rows for the DEM-code add kernel (3072^2 still loses, 3600^2 gains 12 %),
     // >= 18 rows for drain (+11 % on a 1055 x 8190 slab, +15 % at 3072^2, a wash at 2048^2).
-    int pct = 50;
-    if (dem32 && big) pct = 100;
-    if (module == 2 && (long long)(out_last - A0 + 1) * nstrips >= 18LL * slots) pct = 100;
-    if (env_pct > 0) pct = env_pct;
-    if (pct > 0 && pct < 100) slots = slots * pct / 100;
+    if (dem32 && big) two_per_simd = true;
+    if (module == 2 && fast && (long long)(out_last - A0 + 1) * nstrips >= 18LL * slots) two_per_simd = true;
+    if (!two_per_simd && !(module == 2 && !fast)) slots = slots / 2;      /* (the -0.0-safe drain variant is built for one wave per SIMD) */
     if (leave_cus > 0) {                               // room for somebody else's kernels (see wdpm_kernels.h)
       int dev = 0, cus = 256;
       if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -1642,7 +1619,8 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
   int nchunks = (out_last - A0 - 1 + H - 1) / H;
   if (nchunks < 1) nchunks = 1;
   const int nitems = nstrips * nchunks;
-  const dim3 grid(((nitems + 3) / 4 + 7) / 8 * 8), block(256);   // multiple of 8: see the XCD remap
+  const int wpb = two_per_simd ? 8 : 4;                            // waves per workgroup (see the kernel: `prio`)
+  const dim3 grid(((nitems + wpb - 1) / wpb + 7) / 8 * 8), block(64 * wpb);   // multiple of 8: see the XCD remap
   TileFlags tf{nullptr, nullptr, 0, nullptr, nchunks};
   if (tiles && tiles->zout && fast && H >= 6 && A0 == 0 && out_last == g.rows - 1 &&
       (nstrips + 2) * (nchunks + 2) <= tiles->capacity) {
@@ -1662,36 +1640,27 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
   const MaxDiffArgs mda = fold_md ? *md : MaxDiffArgs{nullptr, 0.0, 0, 0, nullptr};
   if (fold_md) tf = TileFlags{nullptr, nullptr, 0, nullptr, nchunks};   /* every wave must look at its block: no skipping in this launch */
   if (fold_md && tiles) tiles->maintained = 0;
-  const int store_plain = env_stores() == 2 || (env_stores() == 0 && module != 2 && (long long)(out_last - A0 + 1) * g.ncp >= 11000000LL);
-  // WDPM_LDS_PAD=<bytes> overrides the padding below (experiments)
-  static std::atomic<int> env_pad{-1};
-  if (env_pad < 0) { const char *e = getenv("WDPM_LDS_PAD"); env_pad = e ? atoi(e) : -2; }
-  // Two workgroups per CU, whatever the register allocator ends up with: the instantiations that stream DEM codes come out at
-  // 166 VGPRs with the priority loop (238 without), which would let the dispatcher stack three workgroups on some CUs and one
-  // on others.  36 KiB of unused dynamic LDS beside the 18 KiB of staging: two fit a CU's 160 KiB, three do not.
-  const int built_for = (module == 2 && !fast) ? 1 : (module != 2 && dem32) ? WDPM_FUSED_CODES_WAVES : WDPM_FUSED_MIN_WAVES;
-  const unsigned lds_pad = env_pad.load(std::memory_order_relaxed) >= 0 ? (unsigned)env_pad.load(std::memory_order_relaxed)
-                                                                        : (built_for <= 2 ? 36864u : 0u);
-#define WDPM_LAUNCH(...) hipLaunchKernelGGL((fused_iteration_kernel<__VA_ARGS__>), grid, block, lds_pad, s, w_in, w_out, dem, code, g, nstrips, nitems, H, A0, out_last, totaldrain, thres, module == 2 ? drain_owed : 0, tf, mda, store_plain, no_clamp)
-#define WDPM_LAUNCH_FM(M, Z, D32) do { if (fold_md) { if (flush) WDPM_LAUNCH(M, Z, D32, true, true); else WDPM_LAUNCH(M, Z, D32, false, true); } \
-                                       else { if (flush) WDPM_LAUNCH(M, Z, D32, true, false); else WDPM_LAUNCH(M, Z, D32, false, false); } } while (0)
-  // tall chunks: the instantiations whose waves lower their issue priority as they advance (see the marching loop)
+  // Workgroups per CU, whatever the register allocator ends up with (an instantiation at 166 VGPRs would let the dispatcher stack
+  // three four-wave workgroups on some CUs and one on others): unused dynamic LDS beside the 36 KiB of staging - four-wave
+  // workgroups 36 KiB (two fit a CU's 160 KiB, three do not), eight-wave workgroups 48 KiB (one fits).
+  const unsigned lds_pad = wpb == 8 ? 49152u : 36864u;
+  // the two waves of a SIMD keep each other in step (see the marching loop); WDPM_PRIO=0: no priorities (A/B, tests)
   static std::atomic<int> env_prio{-1};
   if (env_prio < 0) { const char *e = getenv("WDPM_PRIO"); env_prio = e ? atoi(e) : 1; }
-  const int nsteps = H / 3 + 2;
-  const bool prio = env_prio.load(std::memory_order_relaxed) != 0 && fast && !fold_md &&
-                    (nsteps >= (module == 2 ? 26 : 34) || env_prio.load(std::memory_order_relaxed) == 2);   // WDPM_PRIO=2: whatever the height (tests)
-  if (module == 2 && fast && plain) { if (prio) WDPM_LAUNCH(2, false, false, false, false, true, true); else WDPM_LAUNCH(2, false, false, false, false, true); }
-  else if (module == 2 && fast && prio) { if (flush) WDPM_LAUNCH(2, false, false, true, false, false, true); else WDPM_LAUNCH(2, false, false, false, false, false, true); }
-  else if (module == 2 && fast) { if (flush) WDPM_LAUNCH(2, false, false, true, false); else WDPM_LAUNCH(2, false, false, false, false); }
-  else if (module == 2) WDPM_LAUNCH(2, true, false, false, false);
-  else if (dem32 && prio && plain && env_plain_add()) WDPM_LAUNCH(0, false, true, false, false, true, true);
-  else if (dem32 && prio) { if (flush) WDPM_LAUNCH(0, false, true, true, false, false, true); else WDPM_LAUNCH(0, false, true, false, false, false, true); }
-  else if (dem32) WDPM_LAUNCH_FM(0, false, true);
-  else if (fast && prio) { if (flush) WDPM_LAUNCH(0, false, false, true, false, false, true); else WDPM_LAUNCH(0, false, false, false, false, false, true); }
-  else if (fast) WDPM_LAUNCH_FM(0, false, false);
-  else WDPM_LAUNCH(0, true, false, false, false);
-#undef WDPM_LAUNCH_FM
+  const int prio = (wpb == 8 && env_prio.load(std::memory_order_relaxed) != 0) ? 1 : 0;
+#define WDPM_LAUNCH(...) hipLaunchKernelGGL((fused_iteration_kernel<__VA_ARGS__>), grid, block, lds_pad, s, w_in, w_out, dem, code, g, nstrips, nitems, H, A0, out_last, totaldrain, thres, module == 2 ? drain_owed : 0, tf, mda, prio, no_clamp)
+  // <module, -0.0-safe, DEM codes, flush on load, max diff folded in, gate-free>: which instantiation runs is decided here and
+  // nowhere else (DESIGN.md §4 has the table)
+#define WDPM_LAUNCH_ADD(D32) do { if (fold_md) { if (flush) WDPM_LAUNCH(0, false, D32, true, true); else WDPM_LAUNCH(0, false, D32, false, true); } \
+                                  else if (plain) WDPM_LAUNCH(0, false, D32, false, false, true);                                                   \
+                                  else if (flush) WDPM_LAUNCH(0, false, D32, true, false); else WDPM_LAUNCH(0, false, D32, false, false); } while (0)
+  if (module == 2 && !fast) WDPM_LAUNCH(2, true, false, false, false);
+  else if (module == 2 && plain) WDPM_LAUNCH(2, false, false, false, false, true);
+  else if (module == 2) { if (flush) WDPM_LAUNCH(2, false, false, true, false); else WDPM_LAUNCH(2, false, false, false, false); }
+  else if (!fast) WDPM_LAUNCH(0, true, false, false, false);
+  else if (dem32) WDPM_LAUNCH_ADD(true);
+  else WDPM_LAUNCH_ADD(false);
+#undef WDPM_LAUNCH_ADD
 #undef WDPM_LAUNCH
   return hipGetLastError();
 }

@@ -86,6 +86,32 @@ struct MaxDiffArgs {
   unsigned long long *bits;      /* atomicMax of the bit image of the (non-negative) maximum; zeroed by the caller */
 };
 
+/* Chunk heights that follow what each XCD delivers (round 4).  A marching launch is ONE round of waves, eight equal shares of
+ * work items dealt to the eight XCDs - and the XCDs of a chip are not equally fast: tools/wave_times.py finds their median
+ * wave durations 7 % apart at 16384^2, 11 % on an 8-GPU slab, 19 % at 4096^2 (profiles/r04/wave_times_coop.txt), the same XCDs
+ * slow in every launch on a box and different ones from box to box; the launch ends with the slowest.  So the row boundaries
+ * of the chunks come from a table in device memory - per strip its own - in which a chunk's height is proportional to a
+ * weight of the XCD its work item runs on; waves of measured launches add their duration to a per-XCD sum, and a one-workgroup
+ * kernel on the same stream (xcd_rebalance_kernel: no host round trip) moves the weights towards equal durations and rebuilds the
+ * table.  Results do not depend on where chunks begin (the parity suites run with skewed weights forced: WDPM_BALANCE=2).
+ * Only whole-slab launches of two waves per SIMD without dry-tile flags (a tiling of its own: mostly wet rasters). */
+struct BalanceArgs {             /* kernel argument */
+  const int *table;              /* (nchunks + 1) x nstrips slab rows: chunk c of strip s marches from [c][s] to [c+1][s]; nullptr: equal heights */
+  unsigned long long *acc;       /* [x] += wave duration, [8 + x] += 1 for logical XCD x = blockIdx % 8; nullptr: not measured */
+};
+struct XcdBalance {              /* host side, per context */
+  int *table;                    /* device */
+  unsigned long long *acc;       /* device: 16 cells */
+  float *weight;                 /* device: 8 relative chunk heights, mean 1 */
+  int capacity;                  /* ints `table` has room for */
+  int nstrips, nchunks, A0, out_last, ipx;   /* the launch geometry the table was built for (nstrips == 0: none yet) */
+  int measured;                  /* launches measured since the last rebalance */
+  int measured_uniform;          /* ... and they ran on equal heights (the weights in effect were 1) */
+  int updates;                   /* rebalances so far */
+  long long launches;            /* balanced launches so far (measurement schedule) */
+  int mode;                      /* 0 off, 1 adaptive, 2 adaptive from deliberately skewed weights (tests) */
+};
+
 /* in place: dem <= miss (or NaN) -> +inf.  Every other kernel expects the DEM in this form. */
 hipError_t wdpm_launch_mark_nodata(double *dem, size_t cells, double miss, hipStream_t s);
 /* one colour pass, in place (reference kernels add/subtract/ddrain, runoff.cl:137-183) */
@@ -101,12 +127,12 @@ hipError_t wdpm_launch_pass(int module, double *w, const double *dem, const Slab
 hipError_t wdpm_launch_fused(int module, const double *w_in, double *w_out, const double *dem, const DemCode &code,
                              const SlabGeom &g, int chunk_rows, int signed_zero_safe, const double *flush,
                              int drain_owed, double *totaldrain, hipStream_t s, TilePlan *tiles = nullptr,
-                             const MaxDiffArgs *md = nullptr, int plain_water = 0);
+                             const MaxDiffArgs *md = nullptr, int plain_water = 0, XcdBalance *bal = nullptr);
 hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out, const double *dem,
                                   const DemCode &code, const SlabGeom &g, int A0, int out_last, int chunk_rows,
                                   int signed_zero_safe, const double *flush, int drain_owed, double *totaldrain,
                                   hipStream_t s, TilePlan *tiles = nullptr, const MaxDiffArgs *md = nullptr,
-                                  int leave_cus = 0, int plain_water = 0);
+                                  int leave_cus = 0, int plain_water = 0, XcdBalance *bal = nullptr);
 /* plain_water, bit 0 (WDPM_LAUNCH_PLAIN): the caller knows (wdpm_launch_scan_water, and nothing written since that could change
  * it) that every cell of w_in that may not give water holds +0.0: launches that have such a variant then run without the centre gate.
  * bit 1 (WDPM_LAUNCH_CLAMP_OK): every valid elevation is below 2^30 m in magnitude (wdpm_launch_dem_min), so that half an ulp of an

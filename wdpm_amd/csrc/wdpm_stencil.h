@@ -31,6 +31,20 @@ __device__ __forceinline__ double dem32_decode(const int q, const double k0, con
   return q == (int)0x80000000 ? __builtin_inf() : v;
 }
 
+/* The same for the iteration kernels, one instruction shorter: a NODATA code comes out as a NaN (only the high word is replaced)
+ * instead of +inf.  Every use of an elevation in the add / subtract kernels - the only ones that stream codes - treats the two
+ * alike: as a neighbour, dem + w is NaN / inf, ht is NaN / -inf and nothing moves; as a centre, `dem < inf` is false (the gate,
+ * the max-diff validity test), and in the gate-free variants the centre depth is +0.0 and the flow comes out as 0 through
+ * `NaN > en` = false, x = ht = NaN, max(NaN / 8, -0.0) = -0.0 (clamped: +0.0). */
+__device__ __forceinline__ double dem32_decode_nan(const int q, const double k0, const double D, const double rD) {
+  const double n = (double)q + k0;
+  const double q0 = n * rD;
+  const double r = __builtin_fma(-q0, D, n);
+  const double v = __builtin_fma(r, rD, q0);
+  const int hi = q == (int)0x80000000 ? 0x7ff80000 : __double2hiint(v);
+  return __hiloint2double(hi, __double2loint(v));
+}
+
 /* neighbour k = 0..7 in the reference's visiting order: rowloc outer -1..+1, colloc inner -1..+1,
  * centre skipped (WDPMCL.c:1940-1943) */
 __host__ __device__ constexpr int nb_dr(int k) { return (k < 3) ? -1 : (k < 5 ? 0 : 1); }
