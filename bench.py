@@ -55,7 +55,8 @@ class SharedDem:
         if dist is None:
             self.dem = lib.synth_dem(n, n)
             return
-        run = os.environ.get("TORCHELASTIC_RUN_ID", "") + "_" + os.environ.get("MASTER_PORT", "0")
+        # (the launcher of this file names its runs, so that it can sweep what a killed run left behind: WDPM_BENCH_SHM_TAG)
+        run = os.environ.get("WDPM_BENCH_SHM_TAG", "") + os.environ.get("TORCHELASTIC_RUN_ID", "") + "_" + os.environ.get("MASTER_PORT", "0")
         path = f"/dev/shm/wdpm_bench_{os.getuid()}_{''.join(c for c in run if c.isalnum() or c == '_')}_{n}.npy"
         ok = 1.0
         if local_rank == 0:
@@ -74,6 +75,15 @@ class SharedDem:
         if t.item() > 0:
             self.path = path
             self.dem = np.load(path, mmap_mode="r")
+            # every rank has its mapping (it survives the unlink): the name can go at once, so that a run that is killed later
+            # - the launcher's deadline, a rank that raises - leaves nothing behind in RAM-backed /dev/shm
+            dist.barrier()
+            if self.owner:
+                try:
+                    os.unlink(path)
+                except OSError:
+                    pass
+                self.path = None
         else:
             self.dem = lib.synth_dem(n, n)
 
@@ -107,22 +117,28 @@ class SharedDem:
                 pass
 
 
-def measured_counters(n, world, kernel, dem32):
+def measured_counters(lib, n, world, kernel, dem32):
     """Counter evidence for the dominant kernel from the committed rocprofv3 PMC passes (separate
     --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE runs of this same command,
-    gfx950 x2 FETCH correction, calibrated on kernels of known byte count: profiles/).  Only for the
-    configuration they were taken on; otherwise {}.  With the DEM streamed as 32-bit codes the kernel
-    moves 20 B per cell-update, i.e. LESS than the 24 algorithmic bytes `achieved` is priced at.
+    gfx950 x2 FETCH correction, calibrated on kernels of known byte count: profiles/).  Quoted ONLY for the
+    configuration AND the library build they were taken on: profiles/traffic.json names the build
+    (wdpm_build_info(): a hash of the kernel sources) and the kernel's name; a library built from other kernel
+    sources gets no counters, only the note that the file is of another build.  With the DEM streamed as 32-bit
+    codes the kernel moves 20 B per cell-update, i.e. LESS than the 24 algorithmic bytes `achieved` is priced at.
     -> dict(traffic=HBM bytes per launch, valu_issue_frac=share of the kernel's cycles in which a SIMD issues a VALU
-    instruction (SQ_INSTS_VALU x 4 cycles / SIMDs / (GRBM_GUI_ACTIVE / XCDs)), source=...)"""
+    instruction (SQ_INSTS_VALU x 4 cycles / SIMDs / (GRBM_GUI_ACTIVE / XCDs)), kernel_ms_at_collection, source=...)"""
     path = os.path.join(ROOT, "profiles", "traffic.json")
+    build = lib.dll.wdpm_build_info().decode()
     try:
         with open(path) as f:
             t = json.load(f)
         if t["size"] == n and t["n_gpus"] == world and kernel in ("auto", "fused"):
             e = t["dem32" if dem32 else "fp64_dem"]
+            if e.get("build_info") != build:
+                return {"mismatch": f"profiles/traffic.json is of build [{e.get('build_info')}], this library is [{build}]: no counters quoted"}
             return {"traffic": e["hbm_bytes_per_launch"], "valu_issue_frac": e.get("valu_issue_frac"),
-                    "kernel_ms_at_collection": e.get("kernel_ms"), "source": e.get("source")}
+                    "kernel_ms_at_collection": e.get("kernel_ms"), "kernel_name": e.get("kernel"), "source": e.get("source"),
+                    "build_info": build}
     except (OSError, KeyError, ValueError):
         pass
     return {}
@@ -195,24 +211,27 @@ def oracle_baseline(samples):
     return out
 
 
-def cpu_baseline(full=False):
+def cpu_baseline(n=16384, full=False):
     """The reference's own serial code if its prebuilt library is present (kind "reference"), else the
     CPU oracle (bit-equal port of it, kind "port"), timed on ONE host core (the reference's serial path is
-    single-threaded) on bounded samples of the same workload: SURVEY.md §8d's 1024^2 x 1000 iterations
-    (cache-resident) and 4096^2 x 24 (memory-resident, as the 16384^2 workload is: the headline `value`);
-    `--cpu-baseline-full` adds §8d's 16384^2 x 10 (about a minute) and makes it the headline.
-    A reported baseline, never the product path."""
-    samples = [(4096, 24), (1024, 1000)] + ([(16384, 10)] if full else [])
+    single-threaded) on bounded samples of the same workload.  The headline `value` is on the metric's own
+    configuration: the synthetic 16384^2 raster, 2 iterations of the serial loop (WDPMCL.c:1094-1106; about 13 s at
+    4.2e7 cell-updates/s - SURVEY.md §8d names 10 iterations, which `--cpu-baseline-full` runs: about a minute);
+    beside it §8d's 1024^2 x 1000 iterations (cache-resident; later iterations of a settling raster take the slower
+    branches) and 4096^2 x 24.  A reported baseline, never the product path."""
+    # the headline sample: the bench's own raster size, as many iterations as take about 13 s (never fewer than two)
+    head_iters = 10 if full and n >= 16384 else max(2, min(1000, int(round(5.5e8 / (float(n) * n)))))
+    samples = [(n, head_iters), (4096, 24), (1024, 1000)]
     kind, res = "reference", reference_baseline(samples)
     if res is None:
         kind, res = "port", oracle_baseline(samples)
-    head = res[-1] if full else res[0]
+    head = res[0]
     what = ("runoffs() of the unmodified src/WDPMCL.c (oracle/_ref/libwdpm_ref.so)" if kind == "reference" else
             "oracle/wdpm_oracle.c")
     return {"value": head["value"], "unit": "cell-updates/s", "cores": 1, "kind": kind, "cpu_model": cpu_model(),
             "host_cores": os.cpu_count(),
-            "sample": f"{what}, synthetic {head['size']}x{head['size']} all-wet add 100 mm, {head['iterations']} iterations, "
-                      f"{head['seconds']:.1f} s, one thread (the reference's serial path has no other)",
+            "sample": f"{what}, synthetic {head['size']}x{head['size']} all-wet add 100 mm (the metric's own raster), "
+                      f"{head['iterations']} iterations after one untimed, {head['seconds']:.1f} s, one thread (the reference's serial path has no other)",
             "samples": res}
 
 
@@ -227,11 +246,29 @@ def self_launch(args):
     import signal
     import socket
     import subprocess
+    import glob
     t_start = time.monotonic()
-    budget = float(os.environ.get("WDPM_BENCH_BUDGET_S", "560"))
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    # Time limits: the default command gets the tight pair the driver's 600 s call for - 200 s for the first attempt,
+    # 560 s in all.  A longer job (more steps, a spin-up, a bigger raster) is a healthy run, not a hung one: its limits grow with
+    # the work it was asked for (about 1.5e11 cell-updates/s per GPU, DEM generation and set-up on top), unless the environment
+    # says otherwise (WDPM_BENCH_RANKS_TIMEOUT / WDPM_BENCH_BUDGET_S).
+    size, steps, warm = float(getattr(args, "size", 16384)), getattr(args, "steps", 1000), getattr(args, "warmup", 20)
+    spin = getattr(args, "drain_spinup", 0) if getattr(args, "module", "add") == "drain" else 0
+    expected = 60.0 + size ** 2 / 4.0e7 + size ** 2 * (steps + warm + spin) / (1.0e11 * max(args.gpus, 1))
+    first_default = max(200.0, 2.5 * expected)
+    budget = float(os.environ.get("WDPM_BENCH_BUDGET_S", str(max(560.0, 2.0 * first_default + 60.0) if first_default > 200.0 else 560.0)))
+    shm_tag = f"L{os.getpid()}x{int(time.time()) % 100000}"
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), WDPM_BENCH_SHM_TAG=shm_tag)
     base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}"]
-    first_limit = min(float(os.environ.get("WDPM_BENCH_RANKS_TIMEOUT", "200")), budget)
+    first_limit = min(float(os.environ.get("WDPM_BENCH_RANKS_TIMEOUT", str(first_default))), budget)
+
+    def sweep_shm():
+        """the shared DEM of THIS launcher's ranks, if they were killed before they could unlink it (2.1 GB of RAM each)"""
+        for f in glob.glob(f"/dev/shm/wdpm_bench_{os.getuid()}_{shm_tag}*"):
+            try:
+                os.unlink(f)
+            except OSError:
+                pass
 
     def elapsed():
         return time.monotonic() - t_start
@@ -250,6 +287,7 @@ def self_launch(args):
             except ProcessLookupError:
                 pass
             out, err = p.communicate()
+            sweep_shm()
             return None, out, err
 
     def run(env, limit):
@@ -293,6 +331,7 @@ def self_launch(args):
             except ValueError:
                 pass
         print(line, flush=True)
+    sweep_shm()
     print(f"bench.py: {elapsed():.0f} s of the {budget:.0f} s budget used", file=sys.stderr, flush=True)
     if rc is None:
         return 124
@@ -407,7 +446,8 @@ def main():
         k_used = kk.value
         grp.run_block(args.warmup, THRES)           # untimed warm-up steps (ends with a synchronous reduction)
         e0, x0, _ = grp.enqueue_stats()
-        lib.check(lib.dll.wdpm_timing_reset(ctx0))
+        for i in range(grp.size):
+            lib.check(lib.dll.wdpm_timing_reset(grp.rank_ctx(i)))
         t0 = time.perf_counter()
         max_diff = grp.run_block(args.steps, THRES)  # exactly K timed steps
         if args.module == "drain":
@@ -424,6 +464,13 @@ def main():
         launches, kernel_ms = la.value, ms.value
         lib.check(lib.dll.wdpm_timing_get_steady(ctx0, C.byref(la), C.byref(ms)))
         steady_launches, steady_ms = la.value, ms.value
+        per_rank = []
+        for i in range(grp.size):
+            h, row = grp.rank_ctx(i), {}
+            for key, fn in (("all", lib.dll.wdpm_timing_get), ("steady", lib.dll.wdpm_timing_get_steady), ("xch", lib.dll.wdpm_timing_get_exchange)):
+                lib.check(fn(h, C.byref(la), C.byref(ms)))
+                row[key] = (la.value, ms.value)
+            per_rank.append(row)
         v = C.c_int64()
         lib.check(lib.dll.wdpm_get_option(ctx0, wdpm_amd.OPT_DEM32, C.byref(v)))
         dem32 = bool(v.value) and args.module == "add"
@@ -531,6 +578,12 @@ def main():
         dt = dist_max(dt_mine)
         launches, kernel_ms = solver.ctx.timing()
         steady_launches, steady_ms = solver.ctx.timing_steady()
+        mine = {"all": (launches, kernel_ms), "steady": (steady_launches, steady_ms), "xch": solver.ctx.timing_exchange(),
+                "seconds": dt_mine}
+        per_rank = [mine]
+        if world > 1:
+            per_rank = [None] * world
+            dist.all_gather_object(per_rank, mine)
         dem32 = bool(solver.ctx.get_option(wdpm_amd.OPT_DEM32)) and args.module == "add"
         own_rows0 = solver.slab.own_hi - solver.slab.own_lo + 1 if world > 1 else n
         decomposition = f"row-block x{world}, one process per GPU" if world > 1 else "single GPU"
@@ -549,7 +602,7 @@ def main():
         iter_ms = steady_ms / steady_launches if steady_launches > 0 else all_ms
         achieved = ALGO_BYTES_PER_CELL_UPDATE * own_cells / (iter_ms * 1e-3) / 1e9 if iter_ms > 0 else 0.0
         moved = (20.0 if dem32 else 24.0) * own_cells    # what the kernel really streams (DEM as 4-byte codes or fp64)
-        pmc = measured_counters(n, ranks_used, args.kernel, dem32) if args.module == "add" else {}
+        pmc = measured_counters(lib, n, ranks_used, args.kernel, dem32) if args.module == "add" else {}
         traffic = pmc.get("traffic")
         hbm_real = traffic / (iter_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic and iter_ms > 0 else None
         # VALU issue share as the counters gave it: a share of the kernel's cycles (instructions per launch are a property
@@ -587,7 +640,11 @@ def main():
                          "hbm_real_frac": hbm_real,
                          # share of the kernel's cycles in which a SIMD issues a VALU instruction: the OTHER ceiling
                          "valu_issue_frac": valu,
-                         "counters_source": ("profiles/traffic.json <- " + str(pmc.get("source"))) if pmc else None,
+                         "counters_source": (pmc.get("mismatch") or ("profiles/traffic.json <- " + str(pmc.get("source")))) if pmc else None,
+                         # the counters' own run: the kernel they were read on, its duration there (profiled passes run at a
+                         # lower clock) and the library build - the same as this one, or they would not be quoted
+                         "counters_kernel": pmc.get("kernel_name"), "kernel_ms_at_collection": pmc.get("kernel_ms_at_collection"),
+                         "counters_build": pmc.get("build_info"), "build": lib.dll.wdpm_build_info().decode(),
                          "dem": "32-bit codes, verified lossless on upload (20 B of HBM traffic per cell-update)" if dem32
                                 else "fp64 (24 B of HBM traffic per cell-update)",
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_CELL_UPDATE * own_cells,
@@ -599,11 +656,31 @@ def main():
                          "kernel_ms_per_iteration_all_launches": all_ms,
                          "frac_all_launches": ALGO_BYTES_PER_CELL_UPDATE * own_cells / (all_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if all_ms > 0 else 0.0},
         }
+        if ranks_used > 1:
+            # what an N-GPU line needs to explain its own scaling: per rank, the stencil launches' device time per
+            # iteration (HIP events on the rank's stream; `steady` = the plain instance between a block's first and last launch),
+            # the halo refreshes INTO the rank - how many, and the us on its stream from queueing a transfer to its rows' arrival,
+            # waiting for the neighbour included - and the rank's own wall clock for the timed block
+            def per_iter(row, key):
+                n_l, ms_l = row[key]
+                return ms_l / n_l if n_l else None
+            k_all = [r["all"][1] / max(args.steps, 1) for r in per_rank]
+            out["per_rank"] = {
+                "kernel_ms_per_iteration": k_all,
+                "kernel_ms_per_iteration_steady": [per_iter(r, "steady") for r in per_rank],
+                "refreshes": [r["xch"][0] for r in per_rank],
+                "refresh_us": [r["xch"][1] * 1e3 / r["xch"][0] if r["xch"][0] else None for r in per_rank],
+                "refresh_ms_total": [r["xch"][1] for r in per_rank],
+                "block_seconds": [r.get("seconds") for r in per_rank],
+                "kernel_ms_min_max": [min(k_all), max(k_all)],
+                "note": "refresh_us is measured on the receiving rank's stream: it contains the wait for the sender's kernels; a refresh that "
+                        "hides behind the overlapped interior launch still shows its full length here",
+            }
         if degraded:
             out["degraded"] = True
             out["degraded_reason"] = degraded
         if not args.no_cpu_baseline and ranks_used == 1:   # rank 0 at N=1 only
-            out["cpu_baseline"] = cpu_baseline(full=args.cpu_baseline_full)
+            out["cpu_baseline"] = cpu_baseline(n, full=args.cpu_baseline_full)
         print(json.dumps(out), flush=True)
     if degraded:
         # a helper thread may still sit inside the RCCL call that never came back: leave without running anybody's destructors

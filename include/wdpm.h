@@ -173,6 +173,14 @@ int wdpm_timing_get(wdpm_ctx *ctx, int64_t *launches, double *ms);
  * iterations): the first launch of a block may be the flush-on-load variant of the kernel and the last the max-diff
  * variant, so this is the kernel a profiler lists as the dominant one.  0 launches if there were none. */
 int wdpm_timing_get_steady(wdpm_ctx *ctx, int64_t *launches, double *ms);
+/* ... and of the halo refreshes INTO this context since the last reset: how many, and the time from the point of the
+ * context's stream where a transfer (RCCL group or peer copy) was queued to the point where its rows had arrived - next
+ * to the kernel time, what an N-GPU run needs to explain its scaling (bench.py reports both per rank).  No counterpart in
+ * the reference (one OpenCL device, WDPMCL.c:598-638). */
+int wdpm_timing_get_exchange(wdpm_ctx *ctx, int64_t *refreshes, double *ms);
+/* what this library was built from: "kernels=<first 16 hex digits of the sha256 of the kernel sources> arch=... sched=..." - bench.py
+ * quotes counter evidence collected on another run (profiles/traffic.json) only for a library that says the same */
+const char *wdpm_build_info(void);
 
 /* copy `nrows` rows of the CURRENT water raster from slab-local row `src_row` of `src` to row
  * `dst_row` of `dst` (same raster width).  Device to device on the HIP back-end (peer copy over

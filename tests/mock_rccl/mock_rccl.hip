@@ -23,7 +23,8 @@
  * Fault injection (tests/test_mock_rccl.py) - a rank of a thread group that dies between collectives: MOCK_RCCL_FAIL_RANK=<r>
  * with MOCK_RCCL_FAIL_AFTER=<n> makes that rank's (n+1)-th transfer fail before anything is posted; the product must then end
  * every rank's communicator (ncclCommAbort wakes whoever waits here) and fail, not hang.  For the product's deadlines: MOCK_RCCL_HANG_INIT_RANK=<r> makes that
- * rank's ncclCommInitRank sleep MOCK_RCCL_HANG_S seconds (default 30) before failing; MOCK_RCCL_STALL_RECV_S=<s>
+ * rank's ncclCommInitRank sleep MOCK_RCCL_HANG_S seconds (default 30) before failing; MOCK_RCCL_BLOCK_FIRST_S=<s> keeps the first
+ * transfer of a thread group's rank MOCK_RCCL_BLOCK_RANK inside the call for s seconds; MOCK_RCCL_STALL_RECV_S=<s>
  * makes the FIRST receive of every rank return at once with the stream blocked for s seconds by a host function
  * (a transfer that never completes, as seen from the host), bounded so that nothing can hang the box.
  * Loaded through WDPM_RCCL_LIB by the tests; never part of the product.
@@ -56,6 +57,7 @@ struct World {
   std::vector<Post> box;                 // [src * n + dst]
   bool dead = false;                     // ncclCommAbort on any rank: everybody's waits end with an error
   int group_ends = 0;                    // fault injection: MOCK_RCCL_FAIL_AFTER counts rank MOCK_RCCL_FAIL_RANK's groups
+  bool blocked = false;                  // fault injection: MOCK_RCCL_BLOCK_FIRST_S has had its one call
 };
 
 // ---- one process per rank ------------------------------------------------------------------------------------
@@ -157,6 +159,15 @@ static ncclResult_t group_end_threads(ncclComm *c) {
     std::unique_lock<std::mutex> lk(w->mu);
     if (w->dead) return ncclSystemError;
     if (c->rank == fail_rank && fail_after >= 0 && w->group_ends++ >= fail_after) return ncclSystemError;
+    // fault injection: the FIRST transfer of rank MOCK_RCCL_BLOCK_RANK (default 0) does not come back for MOCK_RCCL_BLOCK_FIRST_S
+    // seconds (a fabric that never answers): the product's deadline for a communicator's first transfer must end the run
+    const double block = env_num("MOCK_RCCL_BLOCK_FIRST_S", 0.0);
+    if (block > 0 && c->rank == (int)env_num("MOCK_RCCL_BLOCK_RANK", 0.0) && !w->blocked) {
+      w->blocked = true;
+      lk.unlock();
+      std::this_thread::sleep_for(std::chrono::milliseconds((long)(block * 1000.0)));
+      return ncclSystemError;
+    }
   }
   // post every send: "my rows are produced once this event fires"
   for (const Op &o : t_ops)

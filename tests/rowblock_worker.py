@@ -26,6 +26,8 @@ def run(rank, world, port, libpath, case, outdir):
         water[dem <= miss] = 0.0
     bd, bw = pad(dem, water, miss)
     kw = dict(case.get("ctx_kw", {}))
+    if case.get("devices"):                       # tests/test_multi_gpu.py: every rank process on a GPU of its own
+        kw["device"] = case["devices"][rank]
     drain = case["module"] == "drain"
     if drain:
         dr, dc = find_drain(bd)

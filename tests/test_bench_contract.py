@@ -43,21 +43,41 @@ def test_bench_line_has_the_contract_fields():
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["value"] > 0 and c["unit"] == "cell-updates/s"
     assert "iterations" in c["sample"] and c["cpu_model"] and c["host_cores"] >= 1
-    # SURVEY §8d's samples: 1024^2 x 1000 always (16384^2 x 10 behind --cpu-baseline-full), next to the headline 4096^2 x 24
-    assert [(x["size"], x["iterations"]) for x in c["samples"]] == [(4096, 24), (1024, 1000)] and c["value"] == c["samples"][0]["value"]
+    # the headline sample is on the bench's own raster (16384^2 x 2 for the default command, x 10 behind --cpu-baseline-full;
+    # here 1024^2 x 524: about 13 s), SURVEY §8d's 4096^2 x 24 and 1024^2 x 1000 beside it
+    assert [(x["size"], x["iterations"]) for x in c["samples"]] == [(1024, 524), (4096, 24), (1024, 1000)] and c["value"] == c["samples"][0]["value"]
+    assert "the metric's own raster" in c["sample"]
 
 
-def test_counter_evidence_is_quoted_for_the_headline_configuration():
+def test_counter_evidence_is_quoted_for_the_headline_configuration_and_build():
     """profiles/traffic.json: HBM bytes and VALU issue share per launch of the dominant kernel, from committed rocprofv3
-    PMC passes of the default command - what `roofline.traffic / hbm_real_frac / valu_issue_frac` quote (no GPU needed)"""
+    PMC passes of the default command - what `roofline.traffic / hbm_real_frac / valu_issue_frac` quote, and ONLY for the
+    library build the passes ran on (wdpm_build_info(): a hash of the kernel sources).  No GPU needed."""
     import importlib.util
+    import wdpm_amd
     spec = importlib.util.spec_from_file_location("bench_counters", os.path.join(ROOT, "bench.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    c = mod.measured_counters(16384, 1, "auto", True)
-    assert 0.8 * 20 * 16384 ** 2 < c["traffic"] < 24 * 16384 ** 2 and 0.5 < c["valu_issue_frac"] < 1.0 and c["kernel_ms_at_collection"] > 0
-    assert os.path.exists(os.path.join(ROOT, c["source"].split(" ")[0]))
-    assert mod.measured_counters(4096, 1, "auto", True) == {} and mod.measured_counters(16384, 2, "auto", True) == {}
+    lib = wdpm_amd.load_hip()
+    build = lib.dll.wdpm_build_info().decode()
+    assert build.startswith("kernels=") and "arch=gfx950" in build
+    with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+        t = json.load(f)
+    c = mod.measured_counters(lib, 16384, 1, "auto", True)
+    if t["dem32"].get("build_info") == build:
+        assert 0.8 * 20 * 16384 ** 2 < c["traffic"] < 24 * 16384 ** 2 and 0.5 < c["valu_issue_frac"] < 1.0 and c["kernel_ms_at_collection"] > 0
+        assert "fused_iteration_kernel" in c["kernel_name"] and c["build_info"] == build
+        assert os.path.exists(os.path.join(ROOT, c["source"].split(" ")[0]))
+    else:     # the kernels have changed since the passes: nothing may be quoted
+        assert set(c) == {"mismatch"} and build in c["mismatch"]
+    assert mod.measured_counters(lib, 4096, 1, "auto", True) == {} and mod.measured_counters(lib, 16384, 2, "auto", True) == {}
+
+    class OtherBuild:          # a library built from other kernel sources never gets these counters
+        class dll:
+            @staticmethod
+            def wdpm_build_info():
+                return b"kernels=0123456789abcdef arch=gfx950 sched=max-ilp"
+    assert set(mod.measured_counters(OtherBuild, 16384, 1, "auto", True)) == {"mismatch"}
 
 
 @gpu

@@ -74,6 +74,30 @@ def test_a_rank_that_fails_between_collectives_ends_the_run(mock_env, tmp_path):
     assert time.time() - t < 60 and not os.path.exists(tmp_path / "out.asc")
 
 
+def test_cli_ends_when_the_first_transfer_never_comes_back(mock_env, tmp_path):
+    """the DEADLINE path of the shipped binary.  WDPMCL on three slabs (one host thread per rank); rank 1's first
+    halo transfer does not return (a fabric that never answers: the stand-in holds the call for a minute).  The library's
+    deadline for a communicator's first transfer (WDPM_RCCL_TIMEOUT_S) ends that wait, the rank's failure ends every rank's
+    communicator, and the command exits non-zero with the reason on stderr and WITHOUT an output raster - the reference
+    exits on any device error (WDPMCL.c:92-118,225-232) - well before the stalled call would have come back"""
+    import gzip
+    import time
+    from conftest import GOLDEN
+    from test_cli import HIP_CLI
+    with gzip.open(os.path.join(GOLDEN, "basin5.asc.gz"), "rb") as f:
+        (tmp_path / "basin5.asc").write_bytes(f.read())
+    env = dict(mock_env, WDPM_DEVICES="0,0,0", WDPM_EXCHANGE_EVERY="3", MOCK_RCCL_BLOCK_FIRST_S="60", MOCK_RCCL_BLOCK_RANK="1",
+               WDPM_RCCL_TIMEOUT_S="5", WDPM_SYNC_TIMEOUT_S="20")
+    t = time.time()
+    p = subprocess.run([HIP_CLI, "add", "basin5.asc", "NULL", "out.asc", "NULL", "100", "1.0", "1.0", "1", "1", "0.005", "2000"],
+                       cwd=tmp_path, capture_output=True, text=True, timeout=120, env=env)
+    took = time.time() - t
+    assert p.returncode not in (0, 42), p.stdout[-500:] + p.stderr[-1500:]
+    assert "the first RCCL halo transfer did not return within 5 s" in p.stderr, p.stderr[-1500:]
+    assert took < 45, f"{took:.0f} s: the command waited for the stalled call"
+    assert not os.path.exists(tmp_path / "out.asc")
+
+
 # ---- one process per rank ---------------------------------------------------------------------------------------
 @pytest.fixture(scope="module")
 def proc_env(mock_env):

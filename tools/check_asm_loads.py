@@ -150,6 +150,15 @@ def main():
         if int(m.group(2)):
             print(f"{m.group(1)[:100]}: {m.group(2)} bytes of scratch")
             bad += 1
+    # ... and none may outgrow the occupancy its launch is sized for: the relay kernels run two eight-wave workgroups per CU at
+    # <= 128 VGPRs (round 4: a second copy of the drain stages took them to 150 - one workgroup per CU, 17 % slower, and every
+    # test still passed); the marching kernel two waves per SIMD at <= 256 (its -0.0-safe drain variant is built for one).
+    for m in re.finditer(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)", text):
+        name, n = m.group(1), int(m.group(2))
+        limit = 128 if "relay_iteration_kernel" in name else (256 if "fused_iteration_kernel" in name and "ILi2ELb1E" not in name else 512)
+        if n > limit:
+            print(f"{name[:100]}: {n} VGPRs, more than the {limit} its launches are sized for")
+            bad += 1
     print("asm prefetch check:", "OK" if not bad else f"{bad} violations")
     sys.exit(1 if bad else 0)
 

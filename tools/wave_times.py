@@ -21,7 +21,7 @@ kw = {}
 if module == "drain":
     k = int(np.argmin(np.where(bd > 0, bd, np.inf))); kw = dict(drainrow=k // (C + 2), draincol=k % (C + 2))
 with lib.context(module=module, nrows=R, ncols=C, missingvalue=-99999.0, kernel=wdpm_amd.KERNEL_FUSED, **kw) as c:
-    c.upload(bd, bw); c.iterate(30); c.synchronize()
+    c.upload(bd, bw); c.run_block(20, 0.0); c.iterate(30); c.synchronize()
     for rep in range(3):
         c.iterate(5); c.synchronize()
         buf = np.zeros((8192, 4), dtype=np.uint64)

@@ -99,6 +99,8 @@ SYMBOLS = {
     "wdpm_timing_reset": (C.c_int, [_vp]),
     "wdpm_timing_get": (C.c_int, [_vp, C.POINTER(C.c_int64), _dp]),
     "wdpm_timing_get_steady": (C.c_int, [_vp, C.POINTER(C.c_int64), _dp]),
+    "wdpm_timing_get_exchange": (C.c_int, [_vp, C.POINTER(C.c_int64), _dp]),
+    "wdpm_build_info": (C.c_char_p, []),
     "wdpm_copy_rows": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, C.c_int32]),
     "wdpm_set_last_error": (None, [C.c_char_p]),
     "wdpm_enable_peer_access": (C.c_int, [_vp, _vp]),
@@ -396,6 +398,12 @@ class Context:
         """(launches, ms) of the launches between the first and the last of each iterate call"""
         n, ms = C.c_int64(), C.c_double()
         self.lib.check(self.lib.dll.wdpm_timing_get_steady(self._h, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+    def timing_exchange(self):
+        """(halo refreshes into this context, ms on its stream from queueing a transfer to its rows' arrival) since the last reset"""
+        n, ms = C.c_int64(), C.c_double()
+        self.lib.check(self.lib.dll.wdpm_timing_get_exchange(self._h, C.byref(n), C.byref(ms)))
         return n.value, ms.value
 
 

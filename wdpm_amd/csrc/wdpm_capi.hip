@@ -265,7 +265,7 @@ int wdpm_create(wdpm_ctx **out, const wdpm_params *p) {
   x->ms = 0.0;
   x->steady_launches = 0;
   x->steady_ms = 0.0;
-  x->timing = false;
+  x->timing = false; x->xch_count = 0; x->xch_ms = 0.0;
   x->comm = nullptr;
   x->leak = false;
   x->d_dem = x->d_w[0] = x->d_w[1] = x->d_w[2] = nullptr;
@@ -275,6 +275,7 @@ int wdpm_create(wdpm_ctx **out, const wdpm_params *p) {
   x->d_active = nullptr; x->h_active = nullptr;
   x->tiles_launched = 0; x->sparse = false; x->stat_tiles = x->stat_active = 0;
   x->wide_tri_ok = false; x->blocks_unprobed = 0;
+  memset(&x->bal, 0, sizeof x->bal);
   { const char *e = getenv("WDPM_TILES"); x->tiles_mode = e ? atoi(e) : 1; }
   x->flush_pending = false;
   x->d_md = nullptr; x->md_hint = x->md_valid = false; x->md_lo = x->md_hi = 0;
@@ -294,8 +295,9 @@ int wdpm_create(wdpm_ctx **out, const wdpm_params *p) {
   if (e == hipSuccess) e = hipStreamCreateWithPriority(&x->side, hipStreamNonBlocking, prio_least);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&x->ev_fork, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&x->ev_join, hipEventDisableTiming);
-  if (e == hipSuccess) e = guarded_malloc(x, (void **)&x->d_dem, bytes);
-  /* + 192 doubles behind each water raster: the fused kernel's dump area for masked-out stores (a strip's width) */
+  if (e == hipSuccess) e = guarded_malloc(x, (void **)&x->d_dem, bytes + 192 * sizeof(double));   /* spare cells: see the water rasters */
+  /* + 192 doubles behind each raster: the fused kernel's dump area for masked-out stores (a strip's width), and what an edge
+   * wave's three-column loads may read past the end of the slab's last row (two cells; the DEM and its codes have spare cells too) */
   if (e == hipSuccess) e = guarded_malloc(x, (void **)&x->d_w[0], bytes + 192 * sizeof(double));
   if (e == hipSuccess) e = guarded_malloc(x, (void **)&x->d_w[1], bytes + 192 * sizeof(double));
   if (e == hipSuccess) e = guarded_malloc(x, (void **)&x->d_w[2], bytes + 192 * sizeof(double));
@@ -303,6 +305,23 @@ int wdpm_create(wdpm_ctx **out, const wdpm_params *p) {
   if (e == hipSuccess) e = hipMalloc(&x->d_scal, 2 * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&x->d_bits, 2 * sizeof(unsigned long long));
   if (e == hipSuccess) e = hipMalloc(&x->d_md, sizeof(unsigned long long));
+  if (e == hipSuccess) {
+    /* chunk heights by what each XCD delivers (wdpm_kernels.h::XcdBalance).  WDPM_BALANCE=0: equal heights always; 2: the table on
+     * launches of any size, starting from deliberately skewed weights (the parity suites under it) */
+    const char *be = getenv("WDPM_BALANCE");
+    x->bal.mode = be ? atoi(be) : 1;
+    if (x->bal.mode < 0 || x->bal.mode > 2) x->bal.mode = 1;
+    x->bal.capacity = 16384;
+    if (x->bal.mode) {
+      static const float even[9] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 0.95f};
+      static const float skew[9] = {0.8f, 1.2f, 0.9f, 1.1f, 1.25f, 0.75f, 1.0f, 1.0f, 0.8f};
+      e = hipMalloc(&x->bal.table, (size_t)x->bal.capacity * sizeof(int));
+      if (e == hipSuccess) e = hipMalloc(&x->bal.acc, 18 * sizeof(unsigned long long));
+      if (e == hipSuccess) e = hipMalloc(&x->bal.weight, 9 * sizeof(float));
+      if (e == hipSuccess) e = hipMemsetAsync(x->bal.acc, 0, 18 * sizeof(unsigned long long), x->stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(x->bal.weight, x->bal.mode == 2 ? skew : even, 9 * sizeof(float), hipMemcpyHostToDevice, x->stream);
+    }
+  }
   {
     /* tile flags: strips of 171 columns x chunks of >= 6 rows */
     x->tile_cap = (x->g.ncp / 171 + 4) * (rows / 6 + 4);
@@ -343,6 +362,7 @@ void wdpm_destroy(wdpm_ctx *x) {
   for (int i = 0; i < 3; i++) guarded_free(x->d_zero[i]);
   (void)hipFree(x->d_active);
   (void)hipFree(x->d_md);
+  (void)hipFree(x->bal.table); (void)hipFree(x->bal.acc); (void)hipFree(x->bal.weight);
   if (x->h_active) (void)hipHostFree(x->h_active);
   if (x->h_pin) (void)hipHostFree(x->h_pin);
   (void)hipFree(x->d_sum_approx); (void)hipFree(x->d_sum_i); (void)hipFree(x->d_sum_k); (void)hipFree(x->d_sum_flag);
@@ -633,11 +653,14 @@ int wdpm_copy_rows(wdpm_ctx *dst, int32_t dst_row, wdpm_ctx *src, int32_t src_ro
   if (!dst->ev_copy[1]) HIP_TRY(hipEventCreateWithFlags(&dst->ev_copy[1], hipEventDisableTiming));
   HIP_TRY(hipStreamWaitEvent(dst->stream, src->ev_copy[0], 0));
   if (tiles_touch(dst, dst->cur, dst_row, nrows)) return 1;       /* queued on dst's stream, ahead of the copy */
+  EventPair xep;
+  if (wdpm_xch_timing_begin(dst, &xep)) return 1;
   const size_t bytes = (size_t)nrows * src->g.ncp * sizeof(double);
   double *d = dst->d_w[dst->cur] + (size_t)dst_row * dst->g.ncp;
   const double *s = src->d_w[src->cur] + (size_t)src_row * src->g.ncp;
   if (src->p.device == dst->p.device) HIP_TRY(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToDevice, dst->stream));
   else HIP_TRY(hipMemcpyPeerAsync(d, dst->p.device, s, src->p.device, bytes, dst->stream));
+  if (wdpm_xch_timing_end(dst, &xep)) return 1;
   HIP_TRY(hipEventRecord(dst->ev_copy[1], dst->stream));
   HIP_TRY(hipSetDevice(src->p.device));
   HIP_TRY(hipStreamWaitEvent(src->stream, dst->ev_copy[1], 0));
@@ -748,6 +771,32 @@ static int fold_timing(wdpm_ctx *x) {
     x->pool.push_back(ep);
   }
   x->pending_steady.clear();
+  for (auto &ep : x->pending_xch) {
+    HIP_TRY(hipEventSynchronize(ep.b));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, ep.a, ep.b));
+    x->xch_ms += ms;
+    x->xch_count += 1;
+    x->pool.push_back(ep);
+  }
+  x->pending_xch.clear();
+  return 0;
+}
+
+int wdpm_xch_timing_begin(wdpm_ctx *x, EventPair *ep) {
+  ep->a = ep->b = nullptr;
+  if (!x->timing) return 0;
+  if (x->pending_xch.size() >= 256 && fold_timing(x)) return 1;
+  if (!x->pool.empty()) { *ep = x->pool.back(); x->pool.pop_back(); }
+  else { HIP_TRY(hipEventCreate(&ep->a)); HIP_TRY(hipEventCreate(&ep->b)); }
+  HIP_TRY(hipEventRecord(ep->a, x->stream));
+  return 0;
+}
+
+int wdpm_xch_timing_end(wdpm_ctx *x, const EventPair *ep) {
+  if (!ep->a) return 0;
+  HIP_TRY(hipEventRecord(ep->b, x->stream));
+  x->pending_xch.push_back(*ep);
   return 0;
 }
 
@@ -800,7 +849,10 @@ int wdpm_iterate(wdpm_ctx *x, int32_t n_iter) {
       const int t = free_slot(x);
       TilePlan tp{x->d_zero[x->cur], x->d_zero[t], x->zero_valid[x->cur] ? 1 : 0, x->zero_valid[t] ? 1 : 0, x->d_active,
                   x->tile_cap, x->tile_nstrips, x->tile_H, x->tile_nchunks, 0, x->wide_tri_ok ? 1 : 0};
-      const bool track = x->tiles_mode != 0 && !x->signed_zero_safe;
+      /* A mostly wet raster (the last block that kept flags found most tiles working) drops the dry-tile flags for chunk heights
+       * that follow the XCDs' speeds (wdpm_kernels.h::XcdBalance): a tiling of its own.  The flags are looked at again every 16 blocks. */
+      const bool balanced = x->bal.mode == 2 || (x->bal.mode == 1 && x->wide_tri_ok);
+      const bool track = x->tiles_mode != 0 && !x->signed_zero_safe && !balanced;
       /* sparse rasters march short chunks: the launch takes as long as its wettest tile */
       const int chunk_rows = x->p.chunk_rows >= 3 ? x->p.chunk_rows : (track && x->sparse ? kSparseChunkRows : 0);
       /* the block's last iteration also reduces max |w - oldw| over the rows the caller announced */
@@ -812,7 +864,7 @@ int wdpm_iterate(wdpm_ctx *x, int32_t n_iter) {
       HIP_TRY(wdpm_launch_fused(x->p.module, x->d_w[x->cur], x->d_w[t], x->d_dem, x->code, x->g, chunk_rows,
                                 x->signed_zero_safe ? 1 : 0, x->flush_pending ? &x->flush_thres : nullptr,
                                 x->drain_owed ? 1 : 0, x->d_scal, x->stream, track ? &tp : nullptr, md.old ? &md : nullptr,
-                                launch_flags(x)));
+                                launch_flags(x), x->bal.mode ? &x->bal : nullptr));
       if (x->flush_pending) flushed_whole(x, x->flush_thres);   /* the launch flushed every value it loaded, and it loaded them all */
       if (md.old) x->md_valid = true;
       if (track && tp.maintained) {
@@ -1073,7 +1125,17 @@ int wdpm_timing_reset(wdpm_ctx *x) {
   x->ms = 0.0;
   x->steady_launches = 0;
   x->steady_ms = 0.0;
+  x->xch_count = 0;
+  x->xch_ms = 0.0;
   x->timing = true;
+  return 0;
+}
+
+int wdpm_timing_get_exchange(wdpm_ctx *x, int64_t *refreshes, double *ms) {
+  if (bind(x)) return 1;
+  if (fold_timing(x)) return 1;
+  if (refreshes) *refreshes = x->xch_count;
+  if (ms) *ms = x->xch_ms;
   return 0;
 }
 

@@ -66,6 +66,7 @@ struct wdpm_ctx {
   int *d_dem32;                 /* the DEM as verified-lossless 32-bit codes (wdpm_kernels.h::DemCode) */
   DemCode code;                 /* code.q == d_dem32 while the uploaded DEM is encodable and the option is on */
   bool dem32_encodable;
+  XcdBalance bal;               /* chunk heights by what each XCD delivers (wdpm_kernels.h); bal.mode == 0: off */
   bool dem_bounded;             /* every valid elevation of the uploaded DEM is below 2^30 m in magnitude (scan_dem): the clamped
                                    neighbour step may run where the depths allow it (wdpm_kernels.h: WDPM_LAUNCH_CLAMP_OK) */
   /* wdpm_iterate_overlapped: side stream for the interior launch and the event that joins it */
@@ -79,6 +80,11 @@ struct wdpm_ctx {
   /* the same for the launches of a call between its first and its last (those two may be the flush-on-load and the
    * max-diff variants of the kernel): what rocprofv3 lists as the dominant kernel */
   std::vector<EventPair> pending_steady;
+  /* halo refreshes (wdpm_comm_exchange, wdpm_copy_rows into this context): from the point of the stream where the transfer is
+   * queued to the point where the rows have arrived - what an N-GPU bench line needs to explain its scaling */
+  std::vector<EventPair> pending_xch;
+  int64_t xch_count;
+  double xch_ms;
   int64_t steady_launches;
   double steady_ms;
   int64_t launches;
@@ -98,5 +104,9 @@ int wdpm_apply_owed_flush(wdpm_ctx *x);   /* that, and the block's threshold flu
 /* hipStreamSynchronize - with a deadline when the context has a communicator (a transfer whose peer has died never completes):
  * WDPM_SYNC_TIMEOUT_S, default 600 s; past it the communicator is aborted, the context is marked `leak` and 1 is returned */
 int wdpm_stream_sync(wdpm_ctx *x, hipStream_t s);
+/* halo-refresh timing (only while wdpm_timing_reset has switched timing on): begin records an event on the context's stream and
+ * returns the pair, end records its second event */
+extern "C" int wdpm_xch_timing_begin(wdpm_ctx *x, EventPair *ep);
+extern "C" int wdpm_xch_timing_end(wdpm_ctx *x, const EventPair *ep);
 
 #endif

@@ -53,6 +53,7 @@
 #include "wdpm_stencil.h"
 
 #include <atomic>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -309,14 +310,12 @@ static __device__ unsigned long long g_wave_times[4 * 8192];   /* one per transl
 #define WDPM_FUSED_CODES_WAVES 2 /* the same for the add / subtract instances that stream the DEM as codes */
 #endif
 
-/* raw registers of the row prefetch.  DEM32: the dem rows arrive as 32-bit codes — interior waves
- * fetch a lane's three columns with one 12-byte load (qi), edge waves column by column (qe).
- * Only the members an instantiation uses exist. */
+/* raw registers of the row prefetch.  DEM32: the dem rows arrive as 32-bit codes, a lane's three columns
+ * in one 12-byte load (qi).  Only the members an instantiation uses exist. */
 typedef int wdpm_i3 __attribute__((ext_vector_type(3)));
 struct Prefetched {
   double NW[3][3], ND[3][3];
   wdpm_i3 qi[3];
-  int qe[3][3];
 };
 
 /* waves per SIMD an instantiation is built for.  The drain variant for rasters that hold a -0.0 depth (SZ_SAFE: the reference's
@@ -332,7 +331,7 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
                        const double *__restrict__ dem, const DemCode code, const SlabGeom g, const int nstrips,
                        const int nitems, const int H, const int A0, const int out_last,
                        double *__restrict__ totaldrain, const double thres, const int drain_owed,
-                       const TileFlags tf, const MaxDiffArgs md, const int prio, const int no_clamp) {
+                       const TileFlags tf, const MaxDiffArgs md, const int prio, const int no_clamp, const BalanceArgs bal) {
   const int lane = threadIdx.x & 63;
   // Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2; placement is only a
   // speed matter, never correctness): give each XCD a contiguous run of work items so that the
@@ -358,10 +357,21 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
   const int oc_lo = strip == 0 ? 0 : c0 + kHaloL;
   const int oc_hi = c0 + kStripIn - 1 - kHaloR;
   // a launch produces the rows [A0 + 2 (0 when A0 == 0), out_last] of the slab; A0 % 3 == 0
-  const int A = A0 + H * chunk;
-  const int nsteps = H / 3 + 2;
+  int A = A0 + H * chunk, A_next = A + H;
+  if (bal.table) {
+    // chunk heights that follow what each XCD delivers (wdpm_kernels.h::BalanceArgs): this strip's own row boundaries.  Whatever
+    // the table holds, no access can leave the slab: A is brought into it, waves near its end take the clamping loads
+    // (`edge`), and rows outside [or_lo, or_hi] - or_hi never beyond out_last - are stored to the dump area.
+    A = bal.table[chunk * nstrips + strip];
+    A_next = bal.table[(chunk + 1) * nstrips + strip];
+    A = A < 0 ? 0 : (A > g.rows ? g.rows : A);
+    const int h = A_next - A;
+    A_next = A + (h < 0 ? 0 : (h > 30000 ? 30000 : h));
+  }
+  const unsigned long long bal_t0 = bal.acc ? wall_clock64() : 0;
+  const int nsteps = (A_next - A) / 3 + 2;
   const int or_lo = A == 0 ? 0 : A + 2;
-  int or_hi = A0 + H * (chunk + 1) + 1;
+  int or_hi = A_next + 1;
   if (or_hi > out_last) or_hi = out_last;
 
   // Dry tiles (wdpm_kernels.h::TileFlags): if this tile and its eight neighbours hold nothing but +0.0 in `win`,
@@ -484,12 +494,13 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
     constexpr bool EDGE = decltype(edge_tag)::value;
     // lane byte offsets inside a row: interior waves use one offset + immediates, edge waves clamp
     // every column into the raster (values of clamped cells are masked on use)
-    int voff[3];
-#pragma unroll
-    for (int j = 0; j < 3; j++) voff[j] = 8 * (EDGE ? (colb + j < g.ncp ? colb + j : g.ncp - 1) : colb);
-    int qoff[3];                     // the same for the 4-byte dem codes
-#pragma unroll
-    for (int j = 0; j < 3; j++) qoff[j] = voff[j] / 2;
+    // Edge waves clamp the row (scalar) and the lane's first column into the raster and read their three columns with the same
+    // one-offset loads as everybody else: a lane whose columns straddle the row's end reads up to two cells past it - the next
+    // row's first cells, or, in the slab's last row, the 192 spare cells behind every raster wdpm_create allocates (16 codes behind
+    // the DEM codes) - and masks them on use, as it masks whole lanes beyond the raster.  (Rounds 1 - 3 clamped column by column:
+    // nine loads per row instead of three, and the edge waves were the last of every launch to end, round 4.)
+    const int voff0 = 8 * (EDGE ? (colb < g.ncp ? colb : g.ncp - 1) : colb);
+    const int qoff0 = voff0 / 2;                     // the same for the 4-byte dem codes
 
     // Prefetch of the three rows starting at r0 into raw registers.  The loads are issued with
     // inline asm (saddr form: wave-uniform row base in SGPRs + a per-lane byte offset) so that
@@ -505,24 +516,15 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
         const double *bw = win + (size_t)r * pitch;     // wave-uniform
         const double *bd = dem + (size_t)r * pitch;
         const int *bq = code.q + (size_t)r * pitch;
-        if (!EDGE) {
-          asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(P.NW[i][0]) : "v"(voff[0]), "s"(bw) : "memory");
-          asm volatile("global_load_dwordx2 %0, %1, %2 offset:8" : "=v"(P.NW[i][1]) : "v"(voff[0]), "s"(bw) : "memory");
-          asm volatile("global_load_dwordx2 %0, %1, %2 offset:16" : "=v"(P.NW[i][2]) : "v"(voff[0]), "s"(bw) : "memory");
-          if (DEM32) {
-            asm volatile("global_load_dwordx3 %0, %1, %2" : "=v"(P.qi[i]) : "v"(qoff[0]), "s"(bq) : "memory");
-          } else {
-            asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(P.ND[i][0]) : "v"(voff[0]), "s"(bd) : "memory");
-            asm volatile("global_load_dwordx2 %0, %1, %2 offset:8" : "=v"(P.ND[i][1]) : "v"(voff[0]), "s"(bd) : "memory");
-            asm volatile("global_load_dwordx2 %0, %1, %2 offset:16" : "=v"(P.ND[i][2]) : "v"(voff[0]), "s"(bd) : "memory");
-          }
+        asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(P.NW[i][0]) : "v"(voff0), "s"(bw) : "memory");
+        asm volatile("global_load_dwordx2 %0, %1, %2 offset:8" : "=v"(P.NW[i][1]) : "v"(voff0), "s"(bw) : "memory");
+        asm volatile("global_load_dwordx2 %0, %1, %2 offset:16" : "=v"(P.NW[i][2]) : "v"(voff0), "s"(bw) : "memory");
+        if (DEM32) {
+          asm volatile("global_load_dwordx3 %0, %1, %2" : "=v"(P.qi[i]) : "v"(qoff0), "s"(bq) : "memory");
         } else {
-#pragma unroll
-          for (int j = 0; j < 3; j++) {
-            asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(P.NW[i][j]) : "v"(voff[j]), "s"(bw) : "memory");
-            if (DEM32) asm volatile("global_load_dword %0, %1, %2" : "=v"(P.qe[i][j]) : "v"(qoff[j]), "s"(bq) : "memory");
-            else asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(P.ND[i][j]) : "v"(voff[j]), "s"(bd) : "memory");
-          }
+          asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(P.ND[i][0]) : "v"(voff0), "s"(bd) : "memory");
+          asm volatile("global_load_dwordx2 %0, %1, %2 offset:8" : "=v"(P.ND[i][1]) : "v"(voff0), "s"(bd) : "memory");
+          asm volatile("global_load_dwordx2 %0, %1, %2 offset:16" : "=v"(P.ND[i][2]) : "v"(voff0), "s"(bd) : "memory");
         }
       }
     };
@@ -539,16 +541,9 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
                      "+v"(P.ND[2][2])                                                                  \
                    :                                                                                   \
                    : "memory");                                                                        \
-    else if (!EDGE)                                                                                    \
-      asm volatile("s_waitcnt vmcnt(" #YOUNGER ")"                                                     \
-                   : WDPM_WAIT_W, "+v"(P.qi[0]), "+v"(P.qi[1]), "+v"(P.qi[2])                          \
-                   :                                                                                   \
-                   : "memory");                                                                        \
     else                                                                                               \
       asm volatile("s_waitcnt vmcnt(" #YOUNGER ")"                                                     \
-                   : WDPM_WAIT_W, "+v"(P.qe[0][0]), "+v"(P.qe[0][1]), "+v"(P.qe[0][2]), "+v"(P.qe[1][0]), \
-                     "+v"(P.qe[1][1]), "+v"(P.qe[1][2]), "+v"(P.qe[2][0]), "+v"(P.qe[2][1]),           \
-                     "+v"(P.qe[2][2])                                                                  \
+                   : WDPM_WAIT_W, "+v"(P.qi[0]), "+v"(P.qi[1]), "+v"(P.qi[2])                          \
                    :                                                                                   \
                    : "memory");                                                                        \
   } while (0)
@@ -599,7 +594,7 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
         for (int j = 0; j < 3; j++) {
           // FLUSH: the block's threshold flush (WDPMCL.c:1059-1062) applied to the water as it arrives
           W[4 + i][j] = FLUSH && P.NW[i][j] < thres ? 0.0 : P.NW[i][j];
-          if (DEM32) D[4 + i][j] = dem32_decode_nan(EDGE ? P.qe[i][j] : P.qi[i][j], code.k0, code.D, code.rD);
+          if (DEM32) D[4 + i][j] = dem32_decode_nan(P.qi[i][j], code.k0, code.D, code.rD);
           else D[4 + i][j] = P.ND[i][j];
         }
       if (MODULE == 2 && owed_here && A + 3 * n + 2 >= g.dr - 1 && A + 3 * n <= g.dr + 1) {   // wave-uniform, rare
@@ -744,6 +739,13 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
     // every staged row went into the mask, the warm-up rows above the block included: a flag of 0 only says "unknown"
     tf.zout[tile] = nzmask ? 0 : 1;
     atomicAdd(tf.active, 1u);
+  }
+  if (bal.acc && lane == 0) {
+    // class 0 .. 7: the XCD (workgroups are dealt round-robin over them); class 8: the waves of a strip's last chunk, whatever
+    // their XCD - they take the clamping loads and the masks of the slab's lower edge on every step and end ~5 % late
+    const int x = chunk == tf.nchunks - 1 ? 8 : (int)(blockIdx.x & 7);
+    atomicAdd(bal.acc + x, wall_clock64() - bal_t0);
+    atomicAdd(bal.acc + 9 + x, 1ull);
   }
 #ifdef WDPM_WAVE_TIMES
   if (lane == 0 && item < 8192) {
@@ -1233,7 +1235,8 @@ relay_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
     if (MODULE == 2 && wo[S0] == wave) {                                                                   \
       stage_impl<2, false, S0, true>(W, D, R0 + S0, g.dr, cdr, ds);                                        \
       if (lane == 0) td_sh[S0] = ds.td;                                                                    \
-    } else if (deep) {                                                                                     \
+    } else if (MODULE == 2 || deep) {      /* drain: never clamped here - the second copy of the stages took the  */ \
+      /* drain instantiations from 112 to 150 VGPRs, one eight-wave workgroup per CU instead of two: -17 % (round 4) */   \
       stage_lockstep<MODULE, 1, S0, 7, PLAIN ? 1 : 0>(W, D);                                               \
     } else {                                                                                               \
       stage_lockstep<MODULE, 1, S0, 7, (PLAIN ? 1 : 0) | 2>(W, D);                                         \
@@ -1338,6 +1341,68 @@ relay_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
     if (wid < 4096) for (int k = 0; k < 8; k++) g_wave_times[8 * wid + k] = rst[k];
   }
 #endif
+}
+
+/* wdpm_kernels.h::XcdBalance: (update) move the weights towards equal mean wave durations - weight 0 .. 7: the relative height of
+ * the chunks whose work items run on that XCD, weight 8: a factor on a strip's last chunk (its waves are the slab's lower edge);
+ * `from_uniform`: the measured launches ran on equal heights, whatever the weights say - then rebuild the table of row boundaries
+ * for the launch geometry given: per strip, heights in proportion to the weights of its chunks, in whole row triples, at least two
+ * per chunk, the last boundary at the launch's last triple.  One workgroup; the sums are cleared for the next measurement. */
+__global__ void __launch_bounds__(256)
+xcd_rebalance_kernel(float *__restrict__ weight, unsigned long long *__restrict__ acc, int *__restrict__ table, const int nstrips,
+                     const int nchunks, const int A0, const int out_last, const int ipx, const int update, const int from_uniform) {
+  __shared__ float w[9];
+  if (threadIdx.x == 0) {
+    float mean[9], m = 0.f;
+    bool all = true;
+    for (int x = 0; x < 9; x++) {
+      const float v = weight[x];
+      w[x] = (v > 0.5f && v < 2.0f) ? v : 1.0f;
+      const unsigned long long n = acc[9 + x];
+      mean[x] = n ? (float)((double)acc[x] / (double)n) : 0.f;
+      if (x < 8) { all = all && n > 0 && mean[x] > 0.f; m += mean[x]; }
+    }
+    if (update && all) {
+      m *= 0.125f;
+      float sum = 0.f;
+      for (int x = 0; x < 9; x++) {
+        if (x == 8 && !(mean[8] > 0.f)) break;
+        const float base = from_uniform ? 1.0f : w[x];
+        float r = m / mean[x];                               // > 1: these waves end early, they can take taller chunks
+        r = r < 0.8f ? 0.8f : (r > 1.25f ? 1.25f : r);
+        w[x] = base * (1.0f + 0.75f * (r - 1.0f));           // damped
+        if (x < 8) sum += w[x];
+      }
+      for (int x = 0; x < 8; x++) {
+        const float v = w[x] * 8.0f / sum;
+        w[x] = v < 0.7f ? 0.7f : (v > 1.4f ? 1.4f : v);
+      }
+      w[8] = w[8] < 0.75f ? 0.75f : (w[8] > 1.2f ? 1.2f : w[8]);
+    }
+    for (int x = 0; x < 9; x++) { weight[x] = w[x]; acc[x] = 0; acc[9 + x] = 0; }
+  }
+  __syncthreads();
+  const int T = (out_last - 1 - A0 + 2) / 3;                 // row triples the chunks of a strip share: A0 + 3 T >= out_last - 1
+  auto wgt = [&](const int c, const int s) {
+    const int x = (c * nstrips + s) / ipx;
+    return w[x < 7 ? x : 7] * (c == nchunks - 1 ? w[8] : 1.0f);
+  };
+  for (int s = (int)threadIdx.x; s < nstrips; s += (int)blockDim.x) {
+    float total = 0.f;
+    for (int c = 0; c < nchunks; c++) total += wgt(c, s);
+    float cum = 0.f;
+    int prev = 0;
+    table[s] = A0;
+    for (int c = 0; c < nchunks; c++) {
+      cum += wgt(c, s);
+      int t = c == nchunks - 1 ? T : (int)((float)T * cum / total + 0.5f);
+      const int lo = prev + 2, hi = T - 2 * (nchunks - 1 - c);
+      t = t < lo ? lo : t;
+      t = t > hi ? hi : t;
+      table[(c + 1) * nstrips + s] = A0 + 3 * t;
+      prev = t;
+    }
+  }
 }
 
 __global__ void dpp_probe_kernel(int *out) {
@@ -1485,8 +1550,11 @@ hipError_t wdpm_launch_small_rows(int module, const double *w_in, double *w_out,
       // of the triangle / marching kernels - add / subtract up to eight rounds (1600^2 20.2 against 24.8 us, 2000^2 28.6 against 33.9,
       // 2400^2 39.0 against 42.4, 3000^2 a tie), drain up to fourteen (3000^2 67 against 78 us, 3600^2 behind) - and where the triangle kernel would run in one
       // round anyway or the raster is known to be mostly wet: like the triangle kernel this one keeps no dry-tile flags (`wide`)
+      // Round 4, after the marching kernel's gains (profiles/r04/relay_breakeven.txt, relay against marching, us per iteration): add
+      // 2000^2 27.5 / 37.8, 2200^2 (7 rounds) 32.6 / 33.3, 2400^2 (8) 38.4 / 37.4, 2700^2 47.8 / 47.1; drain 2400^2 (8) 51.6 / 57.4,
+      // 2700^2 (10) 62.7 / 66.3, 3000^2 (12) 75.9 / 73.6, the 1053 x 8190 slab (12) 74.4 / 72.2: seven and ten rounds.
       const bool relay_ok = env_tri && !signed_zero_safe && chunk_rows < 3 &&
-                            (nwg4 * 4 <= 4 * cus || ((wide || items <= slots_now) && (tall ? r8 : r4) <= (module == 2 ? 14 : 8)) ||
+                            (nwg4 * 4 <= 4 * cus || ((wide || items <= slots_now) && (tall ? r8 : r4) <= (module == 2 ? 10 : 7)) ||
                              env_relay == 2);
       if (env_relay && !fold_md && relay_ok) {
         const dim3 rgrid(((unsigned)nwg + 7) / 8 * 8), rblock(tall ? 512 : 256);
@@ -1544,16 +1612,17 @@ hipError_t wdpm_launch_small_rows(int module, const double *w_in, double *w_out,
 hipError_t wdpm_launch_fused(int module, const double *w_in, double *w_out, const double *dem, const DemCode &code,
                              const SlabGeom &g, int chunk_rows, int signed_zero_safe, const double *flush,
                              int drain_owed, double *totaldrain, hipStream_t s, TilePlan *tiles, const MaxDiffArgs *md,
-                             int plain_water) {
+                             int plain_water, XcdBalance *bal) {
   return wdpm_launch_fused_rows(module, w_in, w_out, dem, code, g, 0, g.rows - 1, chunk_rows, signed_zero_safe, flush,
-                                drain_owed, totaldrain, s, tiles, md, 0, plain_water);
+                                drain_owed, totaldrain, s, tiles, md, 0, plain_water, bal);
 }
 
 /* one iteration restricted to the output rows [A0 + 2 (0 when A0 == 0), out_last]; A0 % 3 == 0 */
 hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out, const double *dem,
                                   const DemCode &code, const SlabGeom &g, int A0, int out_last, int chunk_rows,
                                   int signed_zero_safe, const double *flush, int drain_owed, double *totaldrain,
-                                  hipStream_t s, TilePlan *tiles, const MaxDiffArgs *md, int leave_cus, int plain_water) {
+                                  hipStream_t s, TilePlan *tiles, const MaxDiffArgs *md, int leave_cus, int plain_water,
+                                  XcdBalance *bal) {
   if (tiles) tiles->maintained = 0;
   /* The gate-free variants (PLAIN, see block_update) exist for the launches between a block's first (flush on load) and last
    * (max diff) - of the drain module, which is bound by instruction issue (+4.5 % at 8192^2, +3.8 % at 4096^2), and of the
@@ -1583,7 +1652,16 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
   // ... and only pays on launches big enough for two waves per SIMD (see below): at one wave per SIMD
   // the wave's own latency chain is the limit and the nine decodes per step cost 3-5 % (size sweep in
   // profiles/r01: 512^2 - 3072^2 slower with codes, 4096^2 and up 5-12 % faster).
-  const bool big = (long long)(out_last - A0 + 1) * nstrips >= 36LL * resident_waves<0, false>();
+  // WDPM_TALL_ROWS=<add>,<drain> overrides the two thresholds (chunk height at two waves per SIMD from which a launch fills every slot; tuning)
+  static std::atomic<int> tall_add{0}, tall_drain{0};
+  if (!tall_add) {
+    int a = 36, d = 18;
+    const char *t = getenv("WDPM_TALL_ROWS");
+    if (t) { (void)sscanf(t, "%d,%d", &a, &d); }
+    tall_drain = d >= 3 ? d : 18;
+    tall_add = a >= 3 ? a : 36;
+  }
+  const bool big = (long long)(out_last - A0 + 1) * nstrips >= (long long)tall_add * resident_waves<0, false>();
   const bool dem32 = fast && module != 2 && code.q != nullptr && (big || code.force);
   bool two_per_simd = false;      /* every slot filled: two waves per SIMD, workgroups of eight waves (one per CU) */
   int slots = module == 2 ? (fast ? resident_waves<2, false>() : resident_waves<2, true>())
@@ -1605,7 +1683,7 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
     // two waves per SIMD >= 36 rows for the DEM-code add kernel (3072^2 still loses, 3600^2 gains 12 %),
     // >= 18 rows for drain (+11 % on a 1055 x 8190 slab, +15 % at 3072^2, a wash at 2048^2).
     if (dem32 && big) two_per_simd = true;
-    if (module == 2 && fast && (long long)(out_last - A0 + 1) * nstrips >= 18LL * slots) two_per_simd = true;
+    if (module == 2 && fast && (long long)(out_last - A0 + 1) * nstrips >= (long long)tall_drain * slots) two_per_simd = true;
     if (!two_per_simd && !(module == 2 && !fast)) slots = slots / 2;      /* (the -0.0-safe drain variant is built for one wave per SIMD) */
     if (leave_cus > 0) {                               // room for somebody else's kernels (see wdpm_kernels.h)
       int dev = 0, cus = 256;
@@ -1640,6 +1718,39 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
   const MaxDiffArgs mda = fold_md ? *md : MaxDiffArgs{nullptr, 0.0, 0, 0, nullptr};
   if (fold_md) tf = TileFlags{nullptr, nullptr, 0, nullptr, nchunks};   /* every wave must look at its block: no skipping in this launch */
   if (fold_md && tiles) tiles->maintained = 0;
+  // Chunk heights by what each XCD delivers (wdpm_kernels.h::XcdBalance): whole-slab launches of two waves per SIMD that keep no
+  // dry-tile flags.  Every launch may be measured (the block's first and last are other instantiations: not those); the table
+  // needs chunks of a dozen rows at least, so that whole row triples can follow weights a few per cent apart.
+  BalanceArgs ba{nullptr, nullptr};
+  const bool bal_forced = bal && bal->mode == 2;          /* tests: the table on launches of any size, from skewed weights */
+  if (bal && bal->mode && (two_per_simd || bal_forced) && A0 == 0 && out_last == g.rows - 1 && (chunk_rows < 3 || bal_forced) && nchunks >= 2) {
+    const int ipx = wpb * (int)(grid.x / 8);
+    const bool can_table = !tf.zout && H >= (bal_forced ? 6 : 12) && (nchunks + 1) * nstrips <= bal->capacity;
+    const bool steady = !flush && !fold_md;
+    if (can_table) {
+      const bool same = bal->nstrips == nstrips && bal->nchunks == nchunks && bal->A0 == A0 && bal->out_last == out_last && bal->ipx == ipx;
+      const bool update = bal->measured >= 3 && (same || bal->measured_uniform);
+      if (!same || update) {
+        hipLaunchKernelGGL(xcd_rebalance_kernel, dim3(1), dim3(256), 0, s, bal->weight, bal->acc, bal->table, nstrips, nchunks, A0,
+                           out_last, ipx, update ? 1 : 0, bal->measured_uniform);
+        bal->measured_uniform = 0;
+        bal->nstrips = nstrips; bal->nchunks = nchunks; bal->A0 = A0; bal->out_last = out_last; bal->ipx = ipx;
+        bal->measured = 0;
+        if (update) bal->updates++;
+      }
+      ba.table = bal->table;
+      // measured: while the weights are young, every steady launch (an update every three); afterwards three launches in 256
+      if (steady && (bal->updates < 6 || (bal->launches & 255) < 3)) {
+        if (bal->measured == 0 || !bal->measured_uniform) { ba.acc = bal->acc; bal->measured_uniform = 0; bal->measured++; }
+      }
+      bal->launches++;
+    } else if (steady && bal->updates == 0 && H >= 12 && (bal->measured == 0 || bal->measured_uniform)) {
+      // equal heights (a block that keeps dry-tile flags): what the XCDs deliver can be learnt here already
+      ba.acc = bal->acc;
+      bal->measured_uniform = 1;
+      bal->measured++;
+    }
+  }
   // Workgroups per CU, whatever the register allocator ends up with (an instantiation at 166 VGPRs would let the dispatcher stack
   // three four-wave workgroups on some CUs and one on others): unused dynamic LDS beside the 36 KiB of staging - four-wave
   // workgroups 36 KiB (two fit a CU's 160 KiB, three do not), eight-wave workgroups 48 KiB (one fits).
@@ -1648,7 +1759,7 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
   static std::atomic<int> env_prio{-1};
   if (env_prio < 0) { const char *e = getenv("WDPM_PRIO"); env_prio = e ? atoi(e) : 1; }
   const int prio = (wpb == 8 && env_prio.load(std::memory_order_relaxed) != 0) ? 1 : 0;
-#define WDPM_LAUNCH(...) hipLaunchKernelGGL((fused_iteration_kernel<__VA_ARGS__>), grid, block, lds_pad, s, w_in, w_out, dem, code, g, nstrips, nitems, H, A0, out_last, totaldrain, thres, module == 2 ? drain_owed : 0, tf, mda, prio, no_clamp)
+#define WDPM_LAUNCH(...) hipLaunchKernelGGL((fused_iteration_kernel<__VA_ARGS__>), grid, block, lds_pad, s, w_in, w_out, dem, code, g, nstrips, nitems, H, A0, out_last, totaldrain, thres, module == 2 ? drain_owed : 0, tf, mda, prio, no_clamp, ba)
   // <module, -0.0-safe, DEM codes, flush on load, max diff folded in, gate-free>: which instantiation runs is decided here and
   // nowhere else (DESIGN.md §4 has the table)
 #define WDPM_LAUNCH_ADD(D32) do { if (fold_md) { if (flush) WDPM_LAUNCH(0, false, D32, true, true); else WDPM_LAUNCH(0, false, D32, false, true); } \

@@ -97,12 +97,12 @@ struct MaxDiffArgs {
  * Only whole-slab launches of two waves per SIMD without dry-tile flags (a tiling of its own: mostly wet rasters). */
 struct BalanceArgs {             /* kernel argument */
   const int *table;              /* (nchunks + 1) x nstrips slab rows: chunk c of strip s marches from [c][s] to [c+1][s]; nullptr: equal heights */
-  unsigned long long *acc;       /* [x] += wave duration, [8 + x] += 1 for logical XCD x = blockIdx % 8; nullptr: not measured */
+  unsigned long long *acc;       /* [x] += wave duration, [9 + x] += 1; x = blockIdx % 8, the XCD - or 8 for a strip's last chunk; nullptr: not measured */
 };
 struct XcdBalance {              /* host side, per context */
   int *table;                    /* device */
-  unsigned long long *acc;       /* device: 16 cells */
-  float *weight;                 /* device: 8 relative chunk heights, mean 1 */
+  unsigned long long *acc;       /* device: 18 cells */
+  float *weight;                 /* device: 8 relative chunk heights, mean 1, and the factor on a strip's last chunk */
   int capacity;                  /* ints `table` has room for */
   int nstrips, nchunks, A0, out_last, ipx;   /* the launch geometry the table was built for (nstrips == 0: none yet) */
   int measured;                  /* launches measured since the last rebalance */

@@ -31,6 +31,7 @@
 #include <functional>
 #include <memory>
 #include <mutex>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -115,17 +116,23 @@ struct GuardState {
   int rc = 0;
   char err[512] = "";
 };
-int run_guarded(const std::function<int()> &fn, const char *what, bool *timed_out = nullptr) {
-  const double seconds = env_seconds("WDPM_RCCL_TIMEOUT_S", 90.0);
+int run_guarded(const std::function<int()> &fn, const char *what, bool *timed_out = nullptr, double limit_s = 0.0) {
+  double seconds = env_seconds("WDPM_RCCL_TIMEOUT_S", 90.0);
+  if (limit_s > 0.0 && limit_s < seconds) seconds = limit_s;
   auto st = std::make_shared<GuardState>();
-  std::thread([st, fn] {
-    const int rc = fn();
-    std::lock_guard<std::mutex> lk(st->mu);
-    st->rc = rc;
-    if (rc) snprintf(st->err, sizeof st->err, "%s", wdpm_last_error());
-    st->done = true;
-    st->cv.notify_all();
-  }).detach();
+  if (timed_out) *timed_out = false;
+  try {
+    std::thread([st, fn] {
+      const int rc = fn();
+      std::lock_guard<std::mutex> lk(st->mu);
+      st->rc = rc;
+      if (rc) snprintf(st->err, sizeof st->err, "%s", wdpm_last_error());
+      st->done = true;
+      st->cv.notify_all();
+    }).detach();
+  } catch (const std::system_error &e) {     /* no thread to be had: nothing may cross the extern "C" boundary as an exception */
+    return wdpm_fail("%s: cannot start the helper thread (%s)", what, e.what());
+  }
   std::unique_lock<std::mutex> lk(st->mu);
   const bool ok = st->cv.wait_for(lk, std::chrono::duration<double>(seconds), [&] { return st->done; });
   if (timed_out) *timed_out = !ok;
@@ -142,7 +149,8 @@ struct wdpm_comm {
   double *d_mine, *d_all;   /* wdpm_comm_allgather staging: kGatherMax doubles, nranks * kGatherMax doubles */
   double *h_all;            /* pinned */
   std::atomic<bool> dead;   /* aborted (a deadline passed, or a rank of the group failed): every call fails from now on */
-  bool exchanged, gathered; /* the first transfer / all-gather has come back: later ones are issued directly */
+  std::atomic<bool> exchanged, gathered; /* the first transfer / all-gather has come back: later ones are issued directly (read by
+                                          * the owning thread, but a failing rank of a group may look at any context: atomic) */
 };
 constexpr int kGatherMax = 8;
 
@@ -261,12 +269,17 @@ int wdpm_comm_abort(wdpm_ctx *x) {
   if (!g_api.handle || !c->comm) return 0;
   const ncclComm_t comm = c->comm;
   const int device = x->p.device;
-  /* the abort itself is given a deadline too: it has to talk to a runtime that is, by assumption, in trouble */
+  /* the abort itself is given a deadline too (a short one: the caller has usually just sat out WDPM_RCCL_TIMEOUT_S already) - it
+   * has to talk to a runtime that is, by assumption, in trouble - and it must not replace the reason the caller is about to
+   * report ("the first RCCL halo transfer did not return ...") with its own */
+  char why[512];
+  snprintf(why, sizeof why, "%s", wdpm_last_error());
   (void)run_guarded([=]() -> int {
     (void)hipSetDevice(device);
     (void)(g_api.CommAbort ? g_api.CommAbort(comm) : g_api.CommDestroy(comm));
     return 0;
-  }, "ncclCommAbort");
+  }, "ncclCommAbort", nullptr, 10.0);
+  wdpm_set_last_error(why);
   return 0;
 }
 
@@ -308,7 +321,12 @@ int wdpm_comm_exchange(wdpm_ctx *x, int32_t nsend, const wdpm_halo_op *sends, in
     NCCL_TRY(g_api.GroupEnd());
     return 0;
   };
-  if (c->exchanged) return group();
+  if (c->exchanged) {
+    EventPair xep;
+    if (wdpm_xch_timing_begin(x, &xep)) return 1;
+    if (group()) return 1;
+    return wdpm_xch_timing_end(x, &xep);
+  }
   /* the first transfer of a communicator sets up the peer mappings and the links: with a deadline (see the head of this file) */
   bool timed_out = false;
   const int rc = run_guarded(group, "the first RCCL halo transfer", &timed_out);

@@ -261,6 +261,23 @@ class RowBlockSolver:
         return a.value, b.value
 
 
+def spread_over_devices(ndev: int, nslabs: int | None = None, limit: int = 8) -> list[int]:
+    """The device list of a row-block job on a box with `ndev` GPUs: one slab per GPU, at most `limit` of them
+    (the reference picks one OpenCL device, WDPMCL.c:80-121,598-638; WDPMCL here takes WDPM_GPUS / WDPM_DEVICES) - or, if
+    `nslabs` is given, that many slabs dealt in contiguous runs, so that neighbouring slabs share a device wherever
+    slabs outnumber devices: 8 slabs on 2 GPUs -> [0, 0, 0, 0, 1, 1, 1, 1], 3 on 2 -> [0, 0, 1].  The multi-GPU tests
+    (tests/test_multi_gpu.py) size themselves with this from torch.cuda.device_count()."""
+    if ndev < 1:
+        raise ValueError("no device")
+    use = min(ndev, limit)
+    if nslabs is None:
+        return list(range(use))
+    if nslabs < 1:
+        raise ValueError("no slab")
+    use = min(use, nslabs)
+    return [i * use // nslabs for i in range(nslabs)]
+
+
 class Group:
     """wdpm_group_*: the ranks of ONE process, one host thread per device — what the WDPMCL drop-in
     uses with WDPM_GPUS=N.  devices may repeat (several slabs on one GPU: peer-copy halos)."""
