@@ -49,7 +49,7 @@ def clamped_drain_step(dc, wc, dn, wn, gate, nvalid):
         s = (dce - dnn) + (wcl - wn)
         big = np.where(ht > 0, np.inf, np.where(ht < 0, -np.inf, ht))
         x = np.where(dce > nwe, wcl, vmin(s, big))
-        f = vmin(eighth_clamped(x), wcl)
+        f = eighth_clamped(x)
         return np.where(gate, wcl - np.abs(f), wc), wn + f
 
 

@@ -24,8 +24,9 @@ pytestmark = pytest.mark.gpu
 SUITE = ["tests/test_hip_parity.py::test_golden_stencil_vectors", "tests/test_hip_parity.py::test_random_rasters_match_oracle",
          "tests/test_hip_parity.py::test_dem_codes_on_and_off", "tests/test_hip_parity.py::test_adversarial_operands",
          "tests/test_hip_parity.py::test_drain_outlet_at_every_window_position", "tests/test_hip_parity.py::test_block_loop_matches_oracle",
-         "tests/test_hip_parity.py::test_every_height_around_chunk_boundaries", "tests/test_hip_parity.py::test_water_kinds_and_the_gate_free_variants",
-         "tests/test_clamped_step.py"]
+         "tests/test_hip_parity.py::test_every_height_around_chunk_boundaries", "tests/test_hip_parity.py::test_every_width_around_strip_boundaries",
+         "tests/test_hip_parity.py::test_negative_and_nan_inputs_are_handled_like_the_reference", "tests/test_hip_parity.py::test_degenerate_shapes",
+         "tests/test_hip_parity.py::test_triangle_kernel_in_several_rounds", "tests/test_clamped_step.py"]
 
 VARIANTS = {
     "gated-unclamped-no-priorities": dict(WDPM_PLAIN="0", WDPM_CLAMP="0", WDPM_PRIO="0"),

@@ -51,8 +51,7 @@ def nz_drain_step(dc, wc, dn, wn, gate, nvalid):
         s = (dce - dnn) + (wcl - wn)
         big = np.where(ht > 0, np.inf, np.where(ht < 0, -np.inf, ht))      # v_ldexp_f64(ht, 2200)
         x = np.where(dce > nwe, wcl, vmin(s, big))
-        f = vmax(x * 0.125, np.full_like(x, -0.0))
-        f = vmin(f, wcl)
+        f = vmax(x * 0.125, np.full_like(x, -0.0))          # (the reference's min(flow, w_c) is dead: wdpm_stencil.h, tests/test_step_floor.py)
         return np.where(gate, wcl - np.abs(f), wc), wn + f
 
 
@@ -134,8 +133,8 @@ def test_min_is_a_noop_when_water_moves():
 
 
 def test_nz_drain_form_equals_reference_form():
-    """flow_drain_nz (16 instructions: the sign of ht carried by ldexp, no select on the updates,
-    the outer max dropped) against runoffd()'s conditional form.  The drain sweep only calls it for
+    """flow_drain_nz (15 instructions: the sign of ht carried by ldexp, no select on the updates,
+    the outer max and the min(flow, w_c) dropped) against runoffd()'s conditional form.  The drain sweep only calls it for
     centres with w_c > 0 (WDPMCL.c:1081); negative neighbour depths from odd input files included."""
     rng = np.random.default_rng(17)
     total = 0

@@ -1655,11 +1655,14 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
   // WDPM_TALL_ROWS=<add>,<drain> overrides the two thresholds (chunk height at two waves per SIMD from which a launch fills every slot; tuning)
   static std::atomic<int> tall_add{0}, tall_drain{0};
   if (!tall_add) {
-    int a = 36, d = 18;
+    // Round 4 (profiles/r04/tall_rows_sweep.txt): 18 / 12 rows, where rounds 1 - 3 had 36 / 18 - with the two waves of a SIMD
+    // keeping each other in step and chunk heights following the XCDs, the second wave pays on shorter chunks: add 2700^2 +3.4 %,
+    // 3000^2 +6.7 %, 3300^2 +9.7 %, 3600^2 +2.6 %; drain 2400^2 +2.0 %, 3000^2 +1.1 %.
+    int a = 18, d = 12;
     const char *t = getenv("WDPM_TALL_ROWS");
     if (t) { (void)sscanf(t, "%d,%d", &a, &d); }
-    tall_drain = d >= 3 ? d : 18;
-    tall_add = a >= 3 ? a : 36;
+    tall_drain = d >= 3 ? d : 12;
+    tall_add = a >= 3 ? a : 18;
   }
   const bool big = (long long)(out_last - A0 + 1) * nstrips >= (long long)tall_add * resident_waves<0, false>();
   const bool dem32 = fast && module != 2 && code.q != nullptr && (big || code.force);

@@ -147,14 +147,14 @@ __device__ __forceinline__ void flow_drain(const double dem_c, double &w_c, cons
   w_n = go ? wn2 : w_n;
 }
 
-/* flow_drain_nz — the non-outlet neighbour step of runoffd() in 16 VALU instructions instead of
+/* flow_drain_nz — the non-outlet neighbour step of runoffd() in 15 VALU instructions (14 clamped) instead of
  * 21, bit-identical to flow_drain under flow_add_nz's precondition (no -0.0 depth in the raster;
  * `dem_c` = -inf for a centre that may not give water, NODATA neighbours at dem = +inf).
  *
  *   reference (:1988-2000)                          here
  *   if (ht > 0) {                                   big = ldexp(ht, 2200): +inf / 0 / -inf by sign
  *     flow = dem_c > nwe ? w_c/8 : s/8              x = dem_c > nwe ? w_c : min(s, big);  x/8
- *     flow = min(max(flow, 0.0), w_c)               f = min(max(x/8, -0.0), w_c)
+ *     flow = min(max(flow, 0.0), w_c)               f = max(x/8, -0.0)    (the min is a no-op: see the end of this note)
  *     w_c = max(w_c - flow, 0.0)                    w_c - |f|      (the max is a no-op: f <= w_c)
  *     w_n = w_n + flow }                            w_n + f
  *   with s = (dem_c - dem_n) + (w_c - w_n).
@@ -169,7 +169,19 @@ __device__ __forceinline__ void flow_drain(const double dem_c, double &w_c, cons
  *   x = min(s, big) <= 0 whatever the sign of s (s and ht are rounded differently and may disagree
  *   about the sign of a difference near zero: the reference tests ht, so must we), f = +-0, and
  *   both updates return their inputs.
- * tests/test_stencil_forms.py checks this against the reference form on adversarial operands. */
+ * tests/test_stencil_forms.py checks this against the reference form on adversarial operands.
+ *
+ * Round 4: the reference's min(flow, w_c) of :1998 is a no-op here too, as :1957's is in the add step - it was kept for three
+ * rounds on the belief that s, "rounded differently from ht", might exceed 8 w_c.  It cannot.  Where water moves on the else
+ * branch: w_c > 0, a = fl(dem_c + w_c) > nwe = fl(dem_n + w_n) >= dem_c.  (i) a > nwe means dem_c + w_c reaches the midpoint above
+ * nwe: w_c >= gap/2 + (nwe - dem_c), gap = the spacing of doubles above nwe.  (ii) In real numbers dem_c - dem_n - w_n =
+ * (dem_c - nwe) + (nwe - (dem_n + w_n)) <= -(nwe - dem_c) + gap/2 <= w_c - 2 (nwe - dem_c), so (dem_c - dem_n) + (w_c - w_n) <= 2 w_c.
+ * (iii) The three roundings of s add little on the high side: fl(w_c - w_n) lies above w_c - w_n by at most min(w_c, half a
+ * spacing) - the difference sits on w_n's grid, and w_c is either absorbed (the error is -w_c) or at least half a spacing -
+ * and fl(dem_c - dem_n) <= fl(nwe - dem_n), which is w_n plus the rounding error of nwe (the Fast2Sum identity) plus at most half
+ * a spacing of that; those spacings are gap-sized, i.e. <= 2 w_c by (i).  s <= ~5 w_c in the worst accounting, s / 8 < w_c.
+ * tests/test_step_floor.py hunts for a counter-example over 2 * 10^8 operand tuples built for it (binade boundaries, exact
+ * cancellations of a deep neighbour, subnormals, negative depths): the largest flow / w_c it finds is 0.25 - (ii)'s bound. */
 template <bool CLAMP = false>
 __device__ __forceinline__ void flow_drain_nz(const double dem_c, double &w_c, const double dem_n, double &w_n) {
   const double nwe = dem_n + w_n;                               // :1978
@@ -181,8 +193,8 @@ __device__ __forceinline__ void flow_drain_nz(const double dem_c, double &w_c, c
   // s_cbranch_execz) around EVERY neighbour step - 72 branches per window step, no scheduling across them
   const double m = vmin_f64(s, big);
   const double x = (dem_c > nwe) ? w_c : m;                     // :1990-1996
-  double f = CLAMP ? eighth_clamped(x) : vmax_f64(x * 0.125, -0.0);   // :1998 max(flow, 0.0); NaN -> +-0
-  f = vmin_f64(f, w_c);                                         // :1998 min(.., w_c)
+  const double f = CLAMP ? eighth_clamped(x) : vmax_f64(x * 0.125, -0.0);   // :1998 max(flow, 0.0); NaN -> +-0
+  // :1998 min(.., w_c) is dead (round 4; 16 -> 14 instructions with the clamp): see the note above
   w_c = w_c - __builtin_fabs(f);                                // :1999
   w_n = w_n + f;                                                // :2000
 }
