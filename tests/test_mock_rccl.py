@@ -129,6 +129,19 @@ def test_rank_processes_with_rccl_halos_equal_one_context(oracle, hip, proc_env,
             assert g["stats"].tolist() == ref["_stats"]
 
 
+def test_the_multi_gpu_tests_rehearsed_on_one_gpu(proc_env):
+    """tests/test_multi_gpu.py lights up by itself on a box with two or more GPUs - which this build has never had.  So that the
+    first such lease does not trip over the tests themselves, they run here in a child process that believes in two devices
+    (WDPM_TEST_FAKE_NDEV=2, both mapped onto this GPU) with the stand-in RCCL bound: two ranks through wdpm_comm_init_all and as
+    rank processes, BASELINE configs 4 and 5 at full size on two row blocks over the library's RCCL path against the REFERENCE's
+    bits, bench.py --gpus 2 at 16384^2 with the per-rank attribution.  Everything but the wire."""
+    env = dict(proc_env, WDPM_TEST_FAKE_NDEV="2")
+    p = subprocess.run([sys.executable, "-m", "pytest", "tests/test_multi_gpu.py", "-m", "gpu", "-x", "-q", "-rs", "-p", "no:cacheprovider"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1700)
+    tail = p.stdout.strip().splitlines()[-1] if p.stdout.strip() else ""
+    assert p.returncode == 0 and " passed" in tail and "skipped" not in tail and "failed" not in tail, p.stdout[-4000:] + p.stderr[-2000:]
+
+
 def bench_line(env, *args, timeout=600):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args, "--no-cpu-baseline"], capture_output=True,
                        text=True, timeout=timeout, cwd=ROOT, env=env)
