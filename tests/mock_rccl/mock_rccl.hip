@@ -48,6 +48,7 @@
 #include <vector>
 
 namespace {
+constexpr int kGatherBytes = 1024;       // per rank and all-gather round
 // ---- ranks of one process ------------------------------------------------------------------------------------
 struct Post { const void *buf; size_t bytes; hipEvent_t ready, copied; bool posted, taken; };
 struct World {
@@ -58,11 +59,12 @@ struct World {
   bool dead = false;                     // ncclCommAbort on any rank: everybody's waits end with an error
   int group_ends = 0;                    // fault injection: MOCK_RCCL_FAIL_AFTER counts rank MOCK_RCCL_FAIL_RANK's groups
   bool blocked = false;                  // fault injection: MOCK_RCCL_BLOCK_FIRST_S has had its one call
+  std::vector<uint64_t> gather_seq;      // ncclAllGather between the ranks of one process: round each rank has posted
+  std::vector<unsigned char> gather[2];  // two rounds of n x kGatherBytes (a rank is at most one round ahead of the slowest)
 };
 
 // ---- one process per rank ------------------------------------------------------------------------------------
 constexpr int kMaxRanks = 64;
-constexpr int kGatherBytes = 1024;       // per rank and all-gather round
 struct Mail {                            // one per ordered pair (src, dst), in shared memory
   std::atomic<uint64_t> posted, taken;   // sequence numbers: messages posted by src / read by dst
   hipIpcMemHandle_t handle;              // allocation holding the rows (wire 0)
@@ -109,7 +111,7 @@ template <class F> bool wait_for(Shared *sh, F pred) {
 }
 }  // namespace
 
-struct ncclComm { World *w; int rank; int dev; int n; Proc *proc; };
+struct ncclComm { World *w; int rank; int dev; int n; Proc *proc; uint64_t gather_round = 0; };
 
 static size_t type_size(ncclDataType_t t) { return t == ncclDouble || t == ncclInt64 || t == ncclUint64 ? 8 : (t == ncclFloat || t == ncclInt32 || t == ncclUint32 ? 4 : 1); }
 
@@ -350,6 +352,9 @@ ncclResult_t ncclCommInitAll(ncclComm_t *comm, int n, const int *devs) {
     if (hipEventCreateWithFlags(&w->box[i].ready, hipEventDisableTiming) != hipSuccess) return ncclUnhandledCudaError;
     if (hipEventCreateWithFlags(&w->box[i].copied, hipEventDisableTiming) != hipSuccess) return ncclUnhandledCudaError;
   }
+  w->gather_seq.assign((size_t)n, 0);
+  w->gather[0].assign((size_t)n * kGatherBytes, 0);
+  w->gather[1].assign((size_t)n * kGatherBytes, 0);
   for (int i = 0; i < n; i++) comm[i] = new ncclComm{w, i, devs ? devs[i] : i, n, nullptr};
   return ncclSuccess;
 }
@@ -395,7 +400,35 @@ ncclResult_t ncclGroupEnd() {
   return rc;
 }
 ncclResult_t ncclAllGather(const void *send, void *recv, size_t count, ncclDataType_t t, ncclComm_t c, hipStream_t s) {
-  if (!c->proc) return ncclInvalidUsage;         // the threads of one process share memory: wdpm_group never asks
+  if (!c->proc) {
+    // ranks of one process (ncclCommInitAll), one host thread each - wdpm_group itself never asks (its threads share memory),
+    // tests/test_multi_gpu.py does, as a caller of the real RCCL may
+    World *w = c->w;
+    const size_t nbytes = count * type_size(t);
+    if (nbytes > (size_t)kGatherBytes) return ncclInvalidArgument;
+    std::vector<unsigned char> mine(nbytes), all((size_t)c->n * nbytes);
+    if (hipMemcpyAsync(mine.data(), send, nbytes, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+      return ncclUnhandledCudaError;
+    {
+      std::unique_lock<std::mutex> lk(w->mu);
+      const uint64_t round = ++c->gather_round;
+      std::vector<unsigned char> &slot = w->gather[round & 1];
+      memcpy(slot.data() + (size_t)c->rank * kGatherBytes, mine.data(), nbytes);
+      w->gather_seq[(size_t)c->rank] = round;
+      w->cv.notify_all();
+      const bool ok = w->cv.wait_for(lk, std::chrono::duration<double>(env_num("MOCK_RCCL_TIMEOUT_S", 60.0)), [&] {
+        if (w->dead) return true;
+        for (int q = 0; q < c->n; q++)
+          if (w->gather_seq[(size_t)q] < round) return false;
+        return true;
+      });
+      if (!ok || w->dead) return ncclSystemError;
+      for (int q = 0; q < c->n; q++) memcpy(all.data() + (size_t)q * nbytes, slot.data() + (size_t)q * kGatherBytes, nbytes);
+    }
+    if (hipMemcpyAsync(recv, all.data(), all.size(), hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+      return ncclUnhandledCudaError;
+    return ncclSuccess;
+  }
   Proc *p = c->proc;
   Shared *sh = p->sh;
   const size_t bytes = count * type_size(t);
