@@ -117,7 +117,7 @@ class SharedDem:
                 pass
 
 
-def measured_counters(lib, n, world, kernel, dem32):
+def measured_counters(lib, n, world, kernel, dem_kind):
     """Counter evidence for the dominant kernel from the committed rocprofv3 PMC passes (separate
     --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE runs of this same command,
     gfx950 x2 FETCH correction, calibrated on kernels of known byte count: profiles/).  Quoted ONLY for the
@@ -133,8 +133,9 @@ def measured_counters(lib, n, world, kernel, dem32):
         with open(path) as f:
             t = json.load(f)
         if t["size"] == n and t["n_gpus"] == world and kernel in ("auto", "fused"):
-            e = t["dem32" if dem32 else "fp64_dem"]
-            if e.get("build_info") != build:
+            e = t.get(dem_kind)        # "dem16" | "dem32" | "fp64_dem": how the kernel of this run streams the DEM
+            if e is None or e.get("build_info") != build:
+                e = e or {}
                 return {"mismatch": f"profiles/traffic.json is of build [{e.get('build_info')}], this library is [{build}]: no counters quoted"}
             return {"traffic": e["hbm_bytes_per_launch"], "valu_issue_frac": e.get("valu_issue_frac"),
                     "kernel_ms_at_collection": e.get("kernel_ms"), "kernel_name": e.get("kernel"), "source": e.get("source"),
@@ -474,6 +475,8 @@ def main():
         v = C.c_int64()
         lib.check(lib.dll.wdpm_get_option(ctx0, wdpm_amd.OPT_DEM32, C.byref(v)))
         dem32 = bool(v.value) and args.module == "add"
+        lib.check(lib.dll.wdpm_get_option(ctx0, wdpm_amd.capi.OPT_DEM16, C.byref(v)))
+        dem16 = dem32 and v.value == 1
         sl = wdpm_amd.capi.SlabStruct()
         lib.check(lib.dll.wdpm_rank_slab(lib.dll.wdpm_group_rank(grp._h, 0), 0, C.byref(sl)))
         own_rows0 = sl.own_hi - sl.own_lo + 1 if ranks_used > 1 else n
@@ -585,6 +588,7 @@ def main():
             per_rank = [None] * world
             dist.all_gather_object(per_rank, mine)
         dem32 = bool(solver.ctx.get_option(wdpm_amd.OPT_DEM32)) and args.module == "add"
+        dem16 = dem32 and solver.ctx.get_option(wdpm_amd.capi.OPT_DEM16) == 1     # (2: available, but this slab is too small for them to pay)
         own_rows0 = solver.slab.own_hi - solver.slab.own_lo + 1 if world > 1 else n
         decomposition = f"row-block x{world}, one process per GPU" if world > 1 else "single GPU"
         enqueue_us = refresh_us = None
@@ -601,8 +605,9 @@ def main():
         all_ms = kernel_ms / max(args.steps, 1)
         iter_ms = steady_ms / steady_launches if steady_launches > 0 else all_ms
         achieved = ALGO_BYTES_PER_CELL_UPDATE * own_cells / (iter_ms * 1e-3) / 1e9 if iter_ms > 0 else 0.0
-        moved = (20.0 if dem32 else 24.0) * own_cells    # what the kernel really streams (DEM as 4-byte codes or fp64)
-        pmc = measured_counters(lib, n, ranks_used, args.kernel, dem32) if args.module == "add" else {}
+        # what the kernel really streams: the DEM as fp64, as 4-byte codes, or as 2-byte offsets + one 4-byte base per 48 columns
+        moved = ((16.0 + 2.0 + 4.0 / 48.0) if dem16 else 20.0 if dem32 else 24.0) * own_cells
+        pmc = measured_counters(lib, n, ranks_used, args.kernel, "dem16" if dem16 else "dem32" if dem32 else "fp64_dem") if args.module == "add" else {}
         traffic = pmc.get("traffic")
         hbm_real = traffic / (iter_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic and iter_ms > 0 else None
         # VALU issue share as the counters gave it: a share of the kernel's cycles (instructions per launch are a property
@@ -645,7 +650,9 @@ def main():
                          # lower clock) and the library build - the same as this one, or they would not be quoted
                          "counters_kernel": pmc.get("kernel_name"), "kernel_ms_at_collection": pmc.get("kernel_ms_at_collection"),
                          "counters_build": pmc.get("build_info"), "build": lib.dll.wdpm_build_info().decode(),
-                         "dem": "32-bit codes, verified lossless on upload (20 B of HBM traffic per cell-update)" if dem32
+                         "dem": ("16-bit offsets from one 32-bit base per 48 columns, an exact identity with the 32-bit codes verified "
+                                 "lossless on upload (18.1 B of HBM traffic per cell-update)") if dem16 else
+                                "32-bit codes, verified lossless on upload (20 B of HBM traffic per cell-update)" if dem32
                                 else "fp64 (24 B of HBM traffic per cell-update)",
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_CELL_UPDATE * own_cells,
                          "moved_bytes_per_launch": moved,

@@ -328,6 +328,11 @@ int  wdpm_group_enqueue_stats(wdpm_group *grp, double *seconds, double *exchange
  *   setting 1 is honoured only for a DEM that passed the check; the kernel then uses the codes on
  *   launches large enough for them to pay (>= 4096^2 or so), setting 2 on launches of any size.  WDPM_DEM32=0 in the environment
  *   disables the encoding altogether, WDPM_DEM32=2 makes 2 the default.  The CPU restatement reports 0.
+ * WDPM_OPT_DEM16 (get/set; round 4): 1 = the marching kernel streams those codes as 16-bit offsets from one 32-bit base per 48
+ *   columns of a row (2.08 B per cell: 18.1 B of HBM traffic per cell-update) - an exact integer identity with the verified 32-bit
+ *   codes, possible where no such group spans more than 65 534 quanta; checked at upload, results identical either way.  The get returns
+ *   1 when whole-slab launches of this context use them (from 10^8 cells on, where they pay), 2 when they are available but the
+ *   context is too small for that, 0 when they are off or the terrain does not allow them.
  * WDPM_OPT_WATER_KINDS (get/set; round 3): what the library's scan of every uploaded water raster found, as a bit mask -
  *   1: a -0.0 depth (= WDPM_OPT_SIGNED_ZERO_SAFE), 2: a negative depth (forgotten again once a threshold flush with
  *   thres >= 0 has been applied), 4: NaN, a depth above 1e290 or water on a NODATA cell.  With none of them every cell that
@@ -349,7 +354,7 @@ int  wdpm_group_enqueue_stats(wdpm_group *grp, double *seconds, double *exchange
  *   without the variable).  A debugging aid: the GPU pool has no address sanitizer. */
 enum { WDPM_OPT_SIGNED_ZERO_SAFE = 1, WDPM_OPT_DEM32 = 2, WDPM_OPT_TILES = 3, WDPM_OPT_TILES_SEEN = 4,
        WDPM_OPT_TILES_WORKED = 5, WDPM_OPT_SPARSE = 6, WDPM_OPT_GUARD_BAD = 7, WDPM_OPT_WATER_KINDS = 8,
-       WDPM_OPT_PLAIN_WATER = 9 };
+       WDPM_OPT_PLAIN_WATER = 9, WDPM_OPT_DEM16 = 10 };
 int wdpm_get_option(wdpm_ctx *ctx, int32_t key, int64_t *value);
 int wdpm_set_option(wdpm_ctx *ctx, int32_t key, int64_t value);
 

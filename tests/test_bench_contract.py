@@ -63,21 +63,21 @@ def test_counter_evidence_is_quoted_for_the_headline_configuration_and_build():
     assert build.startswith("kernels=") and "arch=gfx950" in build
     with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
         t = json.load(f)
-    c = mod.measured_counters(lib, 16384, 1, "auto", True)
-    if t["dem32"].get("build_info") == build:
-        assert 0.8 * 20 * 16384 ** 2 < c["traffic"] < 24 * 16384 ** 2 and 0.5 < c["valu_issue_frac"] < 1.0 and c["kernel_ms_at_collection"] > 0
+    c = mod.measured_counters(lib, 16384, 1, "auto", "dem16")
+    if t.get("dem16", {}).get("build_info") == build:
+        assert 0.8 * 18 * 16384 ** 2 < c["traffic"] < 24 * 16384 ** 2 and 0.5 < c["valu_issue_frac"] < 1.0 and c["kernel_ms_at_collection"] > 0
         assert "fused_iteration_kernel" in c["kernel_name"] and c["build_info"] == build
         assert os.path.exists(os.path.join(ROOT, c["source"].split(" ")[0]))
     else:     # the kernels have changed since the passes: nothing may be quoted
         assert set(c) == {"mismatch"} and build in c["mismatch"]
-    assert mod.measured_counters(lib, 4096, 1, "auto", True) == {} and mod.measured_counters(lib, 16384, 2, "auto", True) == {}
+    assert mod.measured_counters(lib, 4096, 1, "auto", "dem16") == {} and mod.measured_counters(lib, 16384, 2, "auto", "dem16") == {}
 
     class OtherBuild:          # a library built from other kernel sources never gets these counters
         class dll:
             @staticmethod
             def wdpm_build_info():
                 return b"kernels=0123456789abcdef arch=gfx950 sched=max-ilp"
-    assert set(mod.measured_counters(OtherBuild, 16384, 1, "auto", True)) == {"mismatch"}
+    assert set(mod.measured_counters(OtherBuild, 16384, 1, "auto", "dem32")) == {"mismatch"}
 
 
 @gpu

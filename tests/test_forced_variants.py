@@ -6,7 +6,7 @@ tools/gpu_r03_*.sh sessions the driver's GPU test never saw).  Here each combina
 stencil golden vectors, the random rasters, the adversarial operand pools, every outlet position of a window and the clamped-step
 cases in a child process (the switches are read once per process), bit for bit against the oracle and the reference's vectors:
 
-  gated, unclamped, no issue priorities      WDPM_PLAIN=0 WDPM_CLAMP=0 WDPM_PRIO=0
+  gated, unclamped, no issue priorities      WDPM_PLAIN=0 WDPM_CLAMP=0 WDPM_PRIO=0 (and no 16-bit DEM offsets: WDPM_DEM16=0)
   the marching kernel on every size          WDPM_RELAY=0 WDPM_TRI=0, DEM codes on every launch (WDPM_DEM32=2), chunk heights from
                                              deliberately skewed per-XCD weights (WDPM_BALANCE=2)
   the relay kernel on every size             WDPM_RELAY=2, four-wave and eight-wave workgroups, stage priorities forced
@@ -22,14 +22,15 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 SUITE = ["tests/test_hip_parity.py::test_golden_stencil_vectors", "tests/test_hip_parity.py::test_random_rasters_match_oracle",
-         "tests/test_hip_parity.py::test_dem_codes_on_and_off", "tests/test_hip_parity.py::test_adversarial_operands",
+         "tests/test_hip_parity.py::test_dem_codes_on_and_off", "tests/test_hip_parity.py::test_dem_codes_as_16_bit_offsets_on_and_off",
+         "tests/test_hip_parity.py::test_adversarial_operands",
          "tests/test_hip_parity.py::test_drain_outlet_at_every_window_position", "tests/test_hip_parity.py::test_block_loop_matches_oracle",
          "tests/test_hip_parity.py::test_every_height_around_chunk_boundaries", "tests/test_hip_parity.py::test_every_width_around_strip_boundaries",
          "tests/test_hip_parity.py::test_negative_and_nan_inputs_are_handled_like_the_reference", "tests/test_hip_parity.py::test_degenerate_shapes",
          "tests/test_hip_parity.py::test_triangle_kernel_in_several_rounds", "tests/test_clamped_step.py"]
 
 VARIANTS = {
-    "gated-unclamped-no-priorities": dict(WDPM_PLAIN="0", WDPM_CLAMP="0", WDPM_PRIO="0"),
+    "gated-unclamped-no-priorities-no-offsets": dict(WDPM_PLAIN="0", WDPM_CLAMP="0", WDPM_PRIO="0", WDPM_DEM16="0"),
     "marching-everywhere-codes-skewed-heights": dict(WDPM_RELAY="0", WDPM_TRI="0", WDPM_DEM32="2", WDPM_BALANCE="2"),
     "relay-everywhere-four-waves": dict(WDPM_RELAY="2", WDPM_RELAY_NW="4", WDPM_RELAY_PRIO="2"),
     "relay-everywhere-eight-waves-codes": dict(WDPM_RELAY="2", WDPM_RELAY_NW="8", WDPM_DEM32="2", WDPM_RELAY_PRIO="2"),

@@ -90,6 +90,61 @@ def test_dem_codes_on_and_off(hip, oracle, module, R, C, chunk, dem32):
                          kernel=wdpm_amd.KERNEL_FUSED, chunk=chunk, dem32=dem32)
 
 
+@pytest.mark.parametrize("module", ["add", "subtract"])
+@pytest.mark.parametrize("R,C,chunk", [(38, 398, 12), (100, 700, 0), (301, 170, 48), (64, 1100, 30), (5, 175, 3), (1, 1, 0)])
+def test_dem_codes_as_16_bit_offsets_on_and_off(hip, oracle, module, R, C, chunk):
+    """round 4: the verified 32-bit codes once more as 16-bit offsets from one base per 48 columns of a row (18.1 B of HBM traffic
+    per cell-update).  Gentle terrain (0.1 m of noise, a slope) is encodable; the kernel must give the same bits with the offsets,
+    with the 32-bit codes and with the fp64 DEM - edge strips, NODATA cells (0xFFFF) and whole NODATA groups included"""
+    rng = np.random.default_rng(R * 1000 + C)
+    miss = -99999.0
+    y, x = np.mgrid[0:R, 0:C]
+    dem = np.round(500.0 + 0.3 * np.sin(x / 5.1) * np.cos(y / 3.3) + rng.normal(0, 0.05, (R, C)) - 0.002 * (x + y), 4)
+    dem[rng.random((R, C)) < 0.05] = miss
+    if C > 200:
+        dem[:, 96:144] = miss                       # a whole group of 48 columns without a valid cell (and the ones beside it cut)
+    water = np.where(dem > miss, np.where(rng.random((R, C)) < 0.3, 0.0, 0.3 * rng.random((R, C))), 0.0)
+    bd, bw = pad(dem, water, miss)
+    kw = dict(module=module, nrows=R, ncols=C, missingvalue=miss)
+    out = {}
+    for mode in ("fp64", "codes32", "codes16"):
+        with hip.context(kernel=wdpm_amd.KERNEL_FUSED, chunk_rows=chunk, **kw) as g:
+            g.upload(bd, bw)
+            can16 = bool((dem > miss).any()) and os.environ.get("WDPM_DEM16", "1") != "0"      # (the forced-variant suites switch it off)
+            assert g.get_option(wdpm_amd.capi.OPT_DEM16) == (2 if can16 else 0)       # available; a raster this small keeps the 32-bit codes
+            g.set_option(wdpm_amd.OPT_DEM32, 0 if mode == "fp64" else 2)                # 2: the codes on launches of any size
+            g.set_option(wdpm_amd.capi.OPT_DEM16, 1 if mode == "codes16" else 0)
+            assert g.get_option(wdpm_amd.capi.OPT_DEM16) == int(mode == "codes16" and can16)
+            g.iterate(7)
+            md = g.run_block(5, 1e-5)
+            out[mode] = (g.download_water(), md)
+    with oracle.context(**kw) as o:
+        o.upload(bd, bw)
+        o.iterate(7)
+        want = (o.run_block(5, 1e-5), o.download_water())
+    for mode, (w, md) in out.items():
+        assert n_bit_diff(w, want[1]) == 0 and md == want[0], mode
+
+
+def test_16_bit_offsets_are_refused_where_the_relief_is_too_steep(hip, oracle):
+    """a group of 48 columns spanning 65 534 quanta is the last one that fits; 65 535 (0xFFFF is NODATA) and more keep the 32-bit codes"""
+    R, C, miss = 40, 300, -99999.0
+    for span, ok in ((65534, 1), (65535, 0), (200001, 0)):      # (quanta of 1e-4 m: the other cells keep e = 4 in charge)
+        dem = np.full((R, C), 500.0003)
+        dem[7, 100] = np.round(500.0003 + span * 1e-4, 4)       # one cell that far above its group
+        dem[3, 50] = miss
+        bd, bw = pad(dem, np.where(dem > miss, 0.05, 0.0), miss)
+        kw = dict(module="add", nrows=R, ncols=C, missingvalue=miss)
+        with hip.context(kernel=wdpm_amd.KERNEL_FUSED, chunk_rows=12, **kw) as g, oracle.context(**kw) as o:
+            g.upload(bd, bw)
+            o.upload(bd, bw)
+            assert g.get_option(wdpm_amd.OPT_DEM32) == 1 and g.get_option(wdpm_amd.capi.OPT_DEM16) == (2 * ok if os.environ.get("WDPM_DEM16", "1") != "0" else 0), span
+            g.set_option(wdpm_amd.OPT_DEM32, 2)
+            g.iterate(6)
+            o.iterate(6)
+            assert n_bit_diff(g.download_water(), o.download_water()) == 0, span
+
+
 def test_dem_codes_are_refused_for_non_decimal_elevations(hip, oracle):
     _compare_with_oracle(hip, oracle, "add", 60, 400, seed=77, iters=(5,), kernel=wdpm_amd.KERNEL_FUSED, dem32=1,
                          dem_digits=None)

@@ -282,7 +282,8 @@ int wdpm_create(wdpm_ctx **out, const wdpm_params *p) {
   x->drain_owed = false;
   x->flush_thres = -__builtin_inf();
   x->d_scal = nullptr; x->d_bits = nullptr; x->h_pin = nullptr; x->d_stat = nullptr;
-  x->d_dem32 = nullptr; x->code = DemCode{nullptr, 0.0, 1.0, 1.0, 0}; x->dem32_encodable = false; x->dem_bounded = false;
+  x->d_dem32 = nullptr; x->code = DemCode{nullptr, 0.0, 1.0, 1.0, 0, nullptr, nullptr, 0}; x->dem32_encodable = false; x->dem_bounded = false;
+  x->d_dem16 = nullptr; x->d_gbase = nullptr; x->dem16_encodable = false;
   x->d_sum_approx = nullptr; x->d_sum_i = nullptr; x->d_sum_k = nullptr; x->d_sum_flag = nullptr;
   x->own_stream = true;
   x->side = nullptr; x->ev_fork = nullptr; x->ev_join = nullptr; x->pending_join = false; x->ev_copy[0] = x->ev_copy[1] = nullptr;
@@ -302,6 +303,8 @@ int wdpm_create(wdpm_ctx **out, const wdpm_params *p) {
   if (e == hipSuccess) e = guarded_malloc(x, (void **)&x->d_w[1], bytes + 192 * sizeof(double));
   if (e == hipSuccess) e = guarded_malloc(x, (void **)&x->d_w[2], bytes + 192 * sizeof(double));
   if (e == hipSuccess) e = guarded_malloc(x, (void **)&x->d_dem32, x->cells * sizeof(int) + 64);
+  if (e == hipSuccess) e = guarded_malloc(x, (void **)&x->d_dem16, x->cells * sizeof(unsigned short) + 64);
+  if (e == hipSuccess) e = guarded_malloc(x, (void **)&x->d_gbase, (size_t)x->g.rows * ((x->g.ncp + kDemGroup - 1) / kDemGroup) * sizeof(int) + 64);
   if (e == hipSuccess) e = hipMalloc(&x->d_scal, 2 * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&x->d_bits, 2 * sizeof(unsigned long long));
   if (e == hipSuccess) e = hipMalloc(&x->d_md, sizeof(unsigned long long));
@@ -359,6 +362,7 @@ void wdpm_destroy(wdpm_ctx *x) {
   for (auto &ep : x->pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
   guarded_free(x->d_dem); guarded_free(x->d_w[0]); guarded_free(x->d_w[1]); guarded_free(x->d_w[2]);
   (void)hipFree(x->d_scal); (void)hipFree(x->d_bits); guarded_free(x->d_dem32); (void)hipFree(x->d_stat);
+  guarded_free(x->d_dem16); guarded_free(x->d_gbase);
   for (int i = 0; i < 3; i++) guarded_free(x->d_zero[i]);
   (void)hipFree(x->d_active);
   (void)hipFree(x->d_md);
@@ -449,8 +453,24 @@ static int encode_dem(wdpm_ctx *x) {
     memcpy(&bad, x->h_pin, sizeof bad);
     if (!bad) {
       x->dem32_encodable = true;
-      x->code = DemCode{x->d_dem32, k0, D, rD, (env && atoi(env) == 2) ? 1 : 0};   /* WDPM_DEM32=2: on launches of any size */
+      x->code = DemCode{x->d_dem32, k0, D, rD, (env && atoi(env) == 2) ? 1 : 0, nullptr, nullptr, 0};   /* WDPM_DEM32=2: on launches of any size */
       break;
+    }
+  }
+  /* second level: the codes as 16-bit offsets from one base per 48 columns of a row - where the terrain allows it (WDPM_DEM16=0: never) */
+  const char *env16 = getenv("WDPM_DEM16");
+  if (x->dem32_encodable && !(env16 && atoi(env16) == 0)) {
+    const int ngroups = (x->g.ncp + kDemGroup - 1) / kDemGroup;
+    HIP_TRY(wdpm_launch_dem16_encode(x->d_dem32, x->g.rows, x->g.ncp, ngroups, x->d_dem16, x->d_gbase, x->d_bits, x->stream));
+    HIP_TRY(hipMemcpyAsync(x->h_pin, x->d_bits, sizeof(double), hipMemcpyDeviceToHost, x->stream));
+    if (wdpm_stream_sync(x, x->stream)) return 1;
+    unsigned long long bad;
+    memcpy(&bad, x->h_pin, sizeof bad);
+    if (!bad) {
+      x->dem16_encodable = true;
+      x->code.h = x->d_dem16;
+      x->code.gb = x->d_gbase;
+      x->code.ngroups = ngroups;
     }
   }
   return 0;
@@ -673,6 +693,7 @@ int wdpm_get_option(wdpm_ctx *x, int32_t key, int64_t *value) {
   else if (key == WDPM_OPT_WATER_KINDS) *value = (x->signed_zero_safe ? WDPM_WATER_NEGZERO : 0) | (x->w_negative ? WDPM_WATER_NEGATIVE : 0) | (x->w_odd ? WDPM_WATER_ODD : 0);
   else if (key == WDPM_OPT_PLAIN_WATER) *value = plain_water(x) ? 1 : 0;
   else if (key == WDPM_OPT_DEM32) *value = x->code.q ? 1 : 0;
+  else if (key == WDPM_OPT_DEM16) *value = x->code.q && x->code.h ? (wdpm_dem16_pays((long long)x->cells, x->code.force) ? 1 : 2) : 0;   /* 2: available, but a whole-slab launch of this size keeps the 32-bit codes */
   else if (key == WDPM_OPT_TILES) *value = x->tiles_mode;
   else if (key == WDPM_OPT_TILES_SEEN) *value = x->stat_tiles;
   else if (key == WDPM_OPT_TILES_WORKED) *value = x->stat_active;
@@ -693,6 +714,8 @@ int wdpm_set_option(wdpm_ctx *x, int32_t key, int64_t value) {
     /* switching it on is honoured only for a DEM that passed the device's bit-for-bit check */
     x->code.q = (value != 0 && x->dem32_encodable) ? x->d_dem32 : nullptr;
     x->code.force = value == 2;   /* 2: also on launches too small for the codes to pay (tests) */
+  } else if (key == WDPM_OPT_DEM16) {
+    x->code.h = (value != 0 && x->dem16_encodable) ? x->d_dem16 : nullptr;
   } else if (key == WDPM_OPT_TILES) {
     x->tiles_mode = value != 0;
     x->zero_valid[0] = x->zero_valid[1] = x->zero_valid[2] = false;

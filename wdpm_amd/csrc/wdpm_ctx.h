@@ -66,6 +66,9 @@ struct wdpm_ctx {
   int *d_dem32;                 /* the DEM as verified-lossless 32-bit codes (wdpm_kernels.h::DemCode) */
   DemCode code;                 /* code.q == d_dem32 while the uploaded DEM is encodable and the option is on */
   bool dem32_encodable;
+  unsigned short *d_dem16;      /* the codes once more as 16-bit offsets from d_gbase (DemCode::h, ::gb); code.h is set while they are in use */
+  int *d_gbase;
+  bool dem16_encodable;
   XcdBalance bal;               /* chunk heights by what each XCD delivers (wdpm_kernels.h); bal.mode == 0: off */
   bool dem_bounded;             /* every valid elevation of the uploaded DEM is below 2^30 m in magnitude (scan_dem): the clamped
                                    neighbour step may run where the depths allow it (wdpm_kernels.h: WDPM_LAUNCH_CLAMP_OK) */

@@ -316,16 +316,19 @@ typedef int wdpm_i3 __attribute__((ext_vector_type(3)));
 struct Prefetched {
   double NW[3][3], ND[3][3];
   wdpm_i3 qi[3];
+  int qh[3][3];      /* DEM32 == 2: 16-bit offsets (zero-extended by the load) ... */
+  int gbv[3];        /* ... and the lane's group base per row */
 };
 
 /* waves per SIMD an instantiation is built for.  The drain variant for rasters that hold a -0.0 depth (SZ_SAFE: the reference's
  * conditional 21-instruction step) does not fit two waves' 256 VGPRs - it spilled 12 bytes in round 3 - and is built for one. */
-template <int MODULE, bool SZ_SAFE, bool DEM32, bool MD>
+template <int MODULE, bool SZ_SAFE, int DEM32, bool MD>
 constexpr int fused_built_for() {
-  return (MODULE == 2 && SZ_SAFE) ? 1 : (MODULE != 2 && DEM32 && !MD && !SZ_SAFE) ? WDPM_FUSED_CODES_WAVES : WDPM_FUSED_MIN_WAVES;
+  return (MODULE == 2 && SZ_SAFE) ? 1 : (MODULE != 2 && DEM32 != 0 && !MD && !SZ_SAFE) ? WDPM_FUSED_CODES_WAVES : WDPM_FUSED_MIN_WAVES;
 }
 
-template <int MODULE, bool SZ_SAFE, bool DEM32, bool FLUSH = false, bool MD = false, bool PLAIN = false>
+/* DEM32: 0 = the fp64 DEM, 1 = verified 32-bit codes, 2 = those as 16-bit offsets + group bases (wdpm_kernels.h::DemCode) */
+template <int MODULE, bool SZ_SAFE, int DEM32, bool FLUSH = false, bool MD = false, bool PLAIN = false>
 __global__ void __launch_bounds__((fused_built_for<MODULE, SZ_SAFE, DEM32, MD>() >= 2 ? 512 : 256), (fused_built_for<MODULE, SZ_SAFE, DEM32, MD>()))
 fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout,
                        const double *__restrict__ dem, const DemCode code, const SlabGeom g, const int nstrips,
@@ -500,7 +503,9 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
     // the DEM codes) - and masks them on use, as it masks whole lanes beyond the raster.  (Rounds 1 - 3 clamped column by column:
     // nine loads per row instead of three, and the edge waves were the last of every launch to end, round 4.)
     const int voff0 = 8 * (EDGE ? (colb < g.ncp ? colb : g.ncp - 1) : colb);
-    const int qoff0 = voff0 / 2;                     // the same for the 4-byte dem codes
+    const int qoff0 = voff0 / 2;                     // the same for the 4-byte dem codes,
+    const int hoff0 = voff0 / 4;                     // the 2-byte offsets
+    const int goff0 = 4 * ((voff0 / 8) / kDemGroup); // and the 4-byte group bases (one per kDemGroup columns)
 
     // Prefetch of the three rows starting at r0 into raw registers.  The loads are issued with
     // inline asm (saddr form: wave-uniform row base in SGPRs + a per-lane byte offset) so that
@@ -516,10 +521,17 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
         const double *bw = win + (size_t)r * pitch;     // wave-uniform
         const double *bd = dem + (size_t)r * pitch;
         const int *bq = code.q + (size_t)r * pitch;
+        const unsigned short *bh = code.h + (size_t)r * pitch;
+        const int *bg = code.gb + (size_t)r * code.ngroups;
         asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(P.NW[i][0]) : "v"(voff0), "s"(bw) : "memory");
         asm volatile("global_load_dwordx2 %0, %1, %2 offset:8" : "=v"(P.NW[i][1]) : "v"(voff0), "s"(bw) : "memory");
         asm volatile("global_load_dwordx2 %0, %1, %2 offset:16" : "=v"(P.NW[i][2]) : "v"(voff0), "s"(bw) : "memory");
-        if (DEM32) {
+        if (DEM32 == 2) {
+          asm volatile("global_load_ushort %0, %1, %2" : "=v"(P.qh[i][0]) : "v"(hoff0), "s"(bh) : "memory");
+          asm volatile("global_load_ushort %0, %1, %2 offset:2" : "=v"(P.qh[i][1]) : "v"(hoff0), "s"(bh) : "memory");
+          asm volatile("global_load_ushort %0, %1, %2 offset:4" : "=v"(P.qh[i][2]) : "v"(hoff0), "s"(bh) : "memory");
+          asm volatile("global_load_dword %0, %1, %2" : "=v"(P.gbv[i]) : "v"(goff0), "s"(bg) : "memory");
+        } else if (DEM32) {
           asm volatile("global_load_dwordx3 %0, %1, %2" : "=v"(P.qi[i]) : "v"(qoff0), "s"(bq) : "memory");
         } else {
           asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(P.ND[i][0]) : "v"(voff0), "s"(bd) : "memory");
@@ -539,6 +551,13 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
                    : WDPM_WAIT_W, "+v"(P.ND[0][0]), "+v"(P.ND[0][1]), "+v"(P.ND[0][2]), "+v"(P.ND[1][0]), \
                      "+v"(P.ND[1][1]), "+v"(P.ND[1][2]), "+v"(P.ND[2][0]), "+v"(P.ND[2][1]),           \
                      "+v"(P.ND[2][2])                                                                  \
+                   :                                                                                   \
+                   : "memory");                                                                        \
+    else if (DEM32 == 2)                                                                               \
+      asm volatile("s_waitcnt vmcnt(" #YOUNGER ")"                                                     \
+                   : WDPM_WAIT_W, "+v"(P.qh[0][0]), "+v"(P.qh[0][1]), "+v"(P.qh[0][2]), "+v"(P.qh[1][0]), "+v"(P.qh[1][1]), \
+                     "+v"(P.qh[1][2]), "+v"(P.qh[2][0]), "+v"(P.qh[2][1]), "+v"(P.qh[2][2]), "+v"(P.gbv[0]), "+v"(P.gbv[1]), \
+                     "+v"(P.gbv[2])                                                                    \
                    :                                                                                   \
                    : "memory");                                                                        \
     else                                                                                               \
@@ -594,7 +613,8 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
         for (int j = 0; j < 3; j++) {
           // FLUSH: the block's threshold flush (WDPMCL.c:1059-1062) applied to the water as it arrives
           W[4 + i][j] = FLUSH && P.NW[i][j] < thres ? 0.0 : P.NW[i][j];
-          if (DEM32) D[4 + i][j] = dem32_decode_nan(P.qi[i][j], code.k0, code.D, code.rD);
+          if (DEM32 == 2) D[4 + i][j] = dem16_decode_nan(P.qh[i][j], P.gbv[i], code.k0, code.D, code.rD);
+          else if (DEM32) D[4 + i][j] = dem32_decode_nan(P.qi[i][j], code.k0, code.D, code.rD);
           else D[4 + i][j] = P.ND[i][j];
         }
       if (MODULE == 2 && owed_here && A + 3 * n + 2 >= g.dr - 1 && A + 3 * n <= g.dr + 1) {   // wave-uniform, rare
@@ -1417,7 +1437,7 @@ __global__ void dpp_probe_kernel(int *out) {
 /* Number of waves of the fused kernel the whole chip holds at once (CUs x blocks/CU x 4 waves),
  * from the occupancy API; cached per module.  All work items of a launch are made resident
  * together — one round, no tail — so the item count is sized to this. */
-template <int MODULE, bool SZ_SAFE, bool DEM32 = false>
+template <int MODULE, bool SZ_SAFE, int DEM32 = 0>
 static int resident_waves() {
   static std::atomic<int> cached{0};      // rank threads of one process launch concurrently: no plain statics
   if (cached.load(std::memory_order_relaxed)) return cached.load(std::memory_order_relaxed);
@@ -1668,7 +1688,7 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
   const bool dem32 = fast && module != 2 && code.q != nullptr && (big || code.force);
   bool two_per_simd = false;      /* every slot filled: two waves per SIMD, workgroups of eight waves (one per CU) */
   int slots = module == 2 ? (fast ? resident_waves<2, false>() : resident_waves<2, true>())
-              : dem32     ? resident_waves<0, false, true>()
+              : dem32     ? resident_waves<0, false, 1>()
               : fast      ? resident_waves<0, false>()
                           : resident_waves<0, true>();
   {
@@ -1768,12 +1788,14 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
 #define WDPM_LAUNCH_ADD(D32) do { if (fold_md) { if (flush) WDPM_LAUNCH(0, false, D32, true, true); else WDPM_LAUNCH(0, false, D32, false, true); } \
                                   else if (plain) WDPM_LAUNCH(0, false, D32, false, false, true);                                                   \
                                   else if (flush) WDPM_LAUNCH(0, false, D32, true, false); else WDPM_LAUNCH(0, false, D32, false, false); } while (0)
-  if (module == 2 && !fast) WDPM_LAUNCH(2, true, false, false, false);
-  else if (module == 2 && plain) WDPM_LAUNCH(2, false, false, false, false, true);
-  else if (module == 2) { if (flush) WDPM_LAUNCH(2, false, false, true, false); else WDPM_LAUNCH(2, false, false, false, false); }
-  else if (!fast) WDPM_LAUNCH(0, true, false, false, false);
-  else if (dem32) WDPM_LAUNCH_ADD(true);
-  else WDPM_LAUNCH_ADD(false);
+  if (module == 2 && !fast) WDPM_LAUNCH(2, true, 0, false, false);
+  else if (module == 2 && plain) WDPM_LAUNCH(2, false, 0, false, false, true);
+  else if (module == 2) { if (flush) WDPM_LAUNCH(2, false, 0, true, false); else WDPM_LAUNCH(2, false, 0, false, false); }
+  else if (!fast) WDPM_LAUNCH(0, true, 0, false, false);
+  // the codes as 16-bit offsets (18.1 B of HBM traffic per cell-update) on launches of 10^8 cells and more: wdpm_kernels.h::wdpm_dem16_pays
+  else if (dem32 && code.h != nullptr && wdpm_dem16_pays((long long)wrows * g.ncp, code.force)) WDPM_LAUNCH_ADD(2);
+  else if (dem32) WDPM_LAUNCH_ADD(1);
+  else WDPM_LAUNCH_ADD(0);
 #undef WDPM_LAUNCH_ADD
 #undef WDPM_LAUNCH
   return hipGetLastError();

@@ -29,7 +29,21 @@ struct DemCode {
   double k0;         /* integer offset: k = q + k0 */
   double D, rD;      /* 10^e and its correctly rounded reciprocal */
   int force;         /* use the codes on launches of any size (tests); normally only where they pay */
+  /* Second level (tried in round 3 at +0.7 % when the kernel was bound by instruction issue alone; kept in round 4, when it
+   * is as close to the memory system's roof): the same codes as 16-bit offsets from one 32-bit base per group of kDemGroup
+   * columns of a row - q[r][c] == gb[r][c / kDemGroup] + h[r][c] for every valid cell, h == 0xFFFF for NODATA - 2.08 B per
+   * cell of HBM traffic instead of 4 (18.1 B per cell-update instead of 20).  Possible when no group of 48 neighbouring cells
+   * of a row spans more than 65 534 quanta (6.5 m of relief at 1e-4 m, 655 m at 1e-2 m); checked for the whole raster when
+   * the DEM is uploaded, else the 32-bit codes stay in charge.  An exact integer identity with the verified 32-bit codes.
+   * A lane's three columns start at a multiple of 3, so they never straddle a group: one base per lane and row. */
+  const unsigned short *h;   /* rows x ncp offsets, or nullptr */
+  const int *gb;             /* rows x ngroups bases */
+  int ngroups;
 };
+constexpr int kDemGroup = 48;
+/* ... and only where it pays: rasters far beyond the 256 MB Infinity Cache, where the bytes are what a launch waits for (16384^2
+ * +2.5 %, 8192^2 +0.3 %, 4096^2 -2.2 %: nine integer adds more per step; profiles/r04/dem16_bench*_ab.txt) - or when forced (tests) */
+inline bool wdpm_dem16_pays(long long cells_of_the_launch, int force) { return cells_of_the_launch >= 100000000LL || force != 0; }
 
 /* smallest valid (finite) dem value, as an order-preserving uint64 key in key[0] (all ones: none), and the bit image of the
  * largest |dem| over the valid cells in key[1] (0: none) */
@@ -38,6 +52,10 @@ double wdpm_dem_key_to_double(unsigned long long key);
 /* q[i] = code of dem[i]; *bad |= 1 if any cell does not decode to exactly dem[i] */
 hipError_t wdpm_launch_dem_encode(const double *dem, size_t cells, double k0, double D, double rD, int *q,
                                   unsigned long long *bad, hipStream_t s);
+
+/* h / gb of DemCode from the verified 32-bit codes q (rows x ncp); *bad |= 1 if some group spans more than 65 534 quanta */
+hipError_t wdpm_launch_dem16_encode(const int *q, int rows, int ncp, int ngroups, unsigned short *h, int *gb,
+                                    unsigned long long *bad, hipStream_t s);
 
 /* The reference's SEQUENTIAL volume sum (WDPMCL.c:1259-1266) evaluated in parallel, see
  * tests/seqsum_model.py: chunks of kSeqSumChunk cells in row-major order.

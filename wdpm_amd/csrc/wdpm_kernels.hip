@@ -231,6 +231,43 @@ hipError_t wdpm_launch_dem_encode(const double *dem, size_t cells, double k0, do
   return hipGetLastError();
 }
 
+// the 32-bit codes as 16-bit offsets from one base per group of kDemGroup columns of a row (DemCode::h, ::gb); one thread
+// per group - a one-off at upload
+__global__ void __launch_bounds__(256)
+dem16_encode_kernel(const int *__restrict__ q, int rows, int ncp, int ngroups, unsigned short *__restrict__ h,
+                    int *__restrict__ gb, unsigned long long *bad) {
+  const size_t total = (size_t)rows * ngroups, stride = (size_t)gridDim.x * blockDim.x;
+  bool miss = false;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int r = (int)(i / ngroups), g = (int)(i % ngroups);
+    const int c0 = g * kDemGroup, c1 = c0 + kDemGroup < ncp ? c0 + kDemGroup : ncp;
+    const int *row = q + (size_t)r * ncp;
+    long long lo = 0x7fffffffLL, hi = -0x80000000LL;
+    for (int c = c0; c < c1; c++) {
+      const int v = row[c];
+      if (v != (int)0x80000000) { lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+    }
+    if (hi < lo) lo = hi = 0;                                  // no valid cell in the group
+    miss |= hi - lo > 65534;
+    gb[i] = (int)lo;
+    for (int c = c0; c < c1; c++) {
+      const int v = row[c];
+      h[(size_t)r * ncp + c] = v == (int)0x80000000 ? (unsigned short)0xFFFF : (unsigned short)((long long)v - lo);
+    }
+  }
+  if (__ballot(miss) && (threadIdx.x & 63) == 0) atomicOr(bad, 1ull);
+}
+
+hipError_t wdpm_launch_dem16_encode(const int *q, int rows, int ncp, int ngroups, unsigned short *h, int *gb,
+                                    unsigned long long *bad, hipStream_t s) {
+  hipError_t e = hipMemsetAsync(bad, 0, sizeof(unsigned long long), s);
+  if (e != hipSuccess || rows <= 0) return e;
+  size_t blocks = ((size_t)rows * ngroups + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(dem16_encode_kernel, dim3((unsigned)blocks), dim3(256), 0, s, q, rows, ncp, ngroups, h, gb, bad);
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------
 // the sequential volume sum in parallel (tests/seqsum_model.py is the model and the proof sketch)
 // ---------------------------------------------------------------------------------------------

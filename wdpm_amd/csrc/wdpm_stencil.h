@@ -45,6 +45,16 @@ __device__ __forceinline__ double dem32_decode_nan(const int q, const double k0,
   return __hiloint2double(hi, __double2loint(v));
 }
 
+/* ... and from a 16-bit offset and its group's base (wdpm_kernels.h::DemCode::h, ::gb): q = gb + h, NODATA is h == 0xFFFF */
+__device__ __forceinline__ double dem16_decode_nan(const int h, const int gb, const double k0, const double D, const double rD) {
+  const double n = (double)(gb + h) + k0;
+  const double q0 = n * rD;
+  const double r = __builtin_fma(-q0, D, n);
+  const double v = __builtin_fma(r, rD, q0);
+  const int hi = h == 0xFFFF ? 0x7ff80000 : __double2hiint(v);
+  return __hiloint2double(hi, __double2loint(v));
+}
+
 /* neighbour k = 0..7 in the reference's visiting order: rowloc outer -1..+1, colloc inner -1..+1,
  * centre skipped (WDPMCL.c:1940-1943) */
 __host__ __device__ constexpr int nb_dr(int k) { return (k < 3) ? -1 : (k < 5 ? 0 : 1); }
