@@ -111,7 +111,8 @@ def test_dem_codes_as_16_bit_offsets_on_and_off(hip, oracle, module, R, C, chunk
         with hip.context(kernel=wdpm_amd.KERNEL_FUSED, chunk_rows=chunk, **kw) as g:
             g.upload(bd, bw)
             can16 = bool((dem > miss).any()) and os.environ.get("WDPM_DEM16", "1") != "0"      # (the forced-variant suites switch it off)
-            assert g.get_option(wdpm_amd.capi.OPT_DEM16) == (2 if can16 else 0)       # available; a raster this small keeps the 32-bit codes
+            small = 1 if os.environ.get("WDPM_DEM32") == "2" else 2                     # 2: available, but a raster this small keeps the 32-bit codes
+            assert g.get_option(wdpm_amd.capi.OPT_DEM16) == (small if can16 else 0)       # (1 under the forced-variant suites' WDPM_DEM32=2)
             g.set_option(wdpm_amd.OPT_DEM32, 0 if mode == "fp64" else 2)                # 2: the codes on launches of any size
             g.set_option(wdpm_amd.capi.OPT_DEM16, 1 if mode == "codes16" else 0)
             assert g.get_option(wdpm_amd.capi.OPT_DEM16) == int(mode == "codes16" and can16)
@@ -138,7 +139,7 @@ def test_16_bit_offsets_are_refused_where_the_relief_is_too_steep(hip, oracle):
         with hip.context(kernel=wdpm_amd.KERNEL_FUSED, chunk_rows=12, **kw) as g, oracle.context(**kw) as o:
             g.upload(bd, bw)
             o.upload(bd, bw)
-            assert g.get_option(wdpm_amd.OPT_DEM32) == 1 and g.get_option(wdpm_amd.capi.OPT_DEM16) == (2 * ok if os.environ.get("WDPM_DEM16", "1") != "0" else 0), span
+            assert g.get_option(wdpm_amd.OPT_DEM32) == 1 and g.get_option(wdpm_amd.capi.OPT_DEM16) == ((1 if os.environ.get("WDPM_DEM32") == "2" else 2) * ok if os.environ.get("WDPM_DEM16", "1") != "0" else 0), span
             g.set_option(wdpm_amd.OPT_DEM32, 2)
             g.iterate(6)
             o.iterate(6)
