@@ -14,7 +14,9 @@ for t in "tests/test_hip_parity.py -k random_call" "tests/test_rowblock.py -k hi
   WDPM_RELAY=2 WDPM_RELAY_NW=8 WDPM_FUZZ_SEEDS=$lo:$hi timeout -k 10 900 python -m pytest $t -m gpu -q -x 2>&1 | tail -n 3
   WDPM_RELAY=0 WDPM_FUZZ_SEEDS=$lo:$hi timeout -k 10 900 python -m pytest $t -m gpu -q -x 2>&1 | tail -n 3
 done
-echo "== the same on the marching kernel alone with its issue-priority instantiations forced (WDPM_PRIO=2 WDPM_RELAY=0 WDPM_TRI=0)"
+echo "== the same on the marching kernel alone (WDPM_RELAY=0 WDPM_TRI=0): chunk heights from skewed per-XCD weights and the DEM codes on every launch (WDPM_BALANCE=2 WDPM_DEM32=2), then gated / unclamped / no priorities / no 16-bit offsets"
 for t in "tests/test_hip_parity.py -k random_call" "tests/test_rowblock.py -k hip_random_group" "tests/test_dry_tiles.py -k random_ponds" "tests/test_hip_parity.py -k every_"; do
-  WDPM_PRIO=2 WDPM_RELAY=0 WDPM_TRI=0 WDPM_FUZZ_SEEDS=$lo:$hi timeout -k 10 900 python -m pytest $t -m gpu -q -x 2>&1 | tail -n 3
+  case "$t" in *dry_tiles*) b="";; *) b="WDPM_BALANCE=2";; esac      # (the forced table drops the dry-tile flags those tests look at)
+  env $b WDPM_DEM32=2 WDPM_RELAY=0 WDPM_TRI=0 WDPM_FUZZ_SEEDS=$lo:$hi timeout -k 10 900 python -m pytest $t -m gpu -q -x 2>&1 | tail -n 3
+  WDPM_PLAIN=0 WDPM_CLAMP=0 WDPM_PRIO=0 WDPM_DEM16=0 WDPM_RELAY=0 WDPM_TRI=0 WDPM_FUZZ_SEEDS=$lo:$hi timeout -k 10 900 python -m pytest $t -m gpu -q -x 2>&1 | tail -n 3
 done

@@ -667,6 +667,11 @@ int wdpm_copy_rows(wdpm_ctx *dst, int32_t dst_row, wdpm_ctx *src, int32_t src_ro
    * outlet lies strictly inside ITS slab - not when the outlet's row is the slab's first or last row, and then the nine
    * cells must arrive zeroed (tests/test_rowblock.py::test_hip_outlet_on_the_last_row_of_the_neighbours_halo). */
   if (ensure_flushed(src)) return 1;   /* ... and the block's threshold flush, should the source still owe it to its raster */
+  /* ... and what kinds of depth the source may hold travel with the rows: a caller who peer-copies rows with a -0.0, a
+   * negative or an odd depth into a context whose own scan was clean must not leave it on the gate-free kernel variants */
+  dst->signed_zero_safe = dst->signed_zero_safe || src->signed_zero_safe;
+  dst->w_negative = dst->w_negative || src->w_negative;
+  dst->w_odd = dst->w_odd || src->w_odd;
   if (!src->ev_copy[0]) HIP_TRY(hipEventCreateWithFlags(&src->ev_copy[0], hipEventDisableTiming));
   HIP_TRY(hipEventRecord(src->ev_copy[0], src->stream));
   if (bind(dst)) return 1;

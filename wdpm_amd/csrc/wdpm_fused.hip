@@ -53,7 +53,6 @@
 #include "wdpm_stencil.h"
 
 #include <atomic>
-#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -1672,18 +1671,11 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
   // ... and only pays on launches big enough for two waves per SIMD (see below): at one wave per SIMD
   // the wave's own latency chain is the limit and the nine decodes per step cost 3-5 % (size sweep in
   // profiles/r01: 512^2 - 3072^2 slower with codes, 4096^2 and up 5-12 % faster).
-  // WDPM_TALL_ROWS=<add>,<drain> overrides the two thresholds (chunk height at two waves per SIMD from which a launch fills every slot; tuning)
-  static std::atomic<int> tall_add{0}, tall_drain{0};
-  if (!tall_add) {
-    // Round 4 (profiles/r04/tall_rows_sweep.txt): 18 / 12 rows, where rounds 1 - 3 had 36 / 18 - with the two waves of a SIMD
-    // keeping each other in step and chunk heights following the XCDs, the second wave pays on shorter chunks: add 2700^2 +3.4 %,
-    // 3000^2 +6.7 %, 3300^2 +9.7 %, 3600^2 +2.6 %; drain 2400^2 +2.0 %, 3000^2 +1.1 %.
-    int a = 18, d = 12;
-    const char *t = getenv("WDPM_TALL_ROWS");
-    if (t) { (void)sscanf(t, "%d,%d", &a, &d); }
-    tall_drain = d >= 3 ? d : 12;
-    tall_add = a >= 3 ? a : 18;
-  }
+  // Chunk height at two waves per SIMD from which a launch fills every slot: 18 rows (add / subtract), 12 (drain).  Rounds 1 - 3 had
+  // 36 / 18; with the two waves of a SIMD keeping each other in step and chunk heights following the XCDs, the second wave pays on
+  // shorter chunks: add 2700^2 +3.4 %, 3000^2 +6.7 %, 3300^2 +9.7 %, 3600^2 +2.6 %; drain 2400^2 +2.0 %, 3000^2 +1.1 %
+  // (profiles/r04/tall_rows_sweep.txt).
+  constexpr long long tall_add = 18, tall_drain = 12;
   const bool big = (long long)(out_last - A0 + 1) * nstrips >= (long long)tall_add * resident_waves<0, false>();
   const bool dem32 = fast && module != 2 && code.q != nullptr && (big || code.force);
   bool two_per_simd = false;      /* every slot filled: two waves per SIMD, workgroups of eight waves (one per CU) */
@@ -1777,7 +1769,18 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
   // Workgroups per CU, whatever the register allocator ends up with (an instantiation at 166 VGPRs would let the dispatcher stack
   // three four-wave workgroups on some CUs and one on others): unused dynamic LDS beside the 36 KiB of staging - four-wave
   // workgroups 36 KiB (two fit a CU's 160 KiB, three do not), eight-wave workgroups 48 KiB (one fits).
-  const unsigned lds_pad = wpb == 8 ? 49152u : 36864u;
+  // The pad follows the CU's LDS (not a constant tied to one architecture): an eight-wave workgroup takes just over half
+  // of it, a four-wave one just over a third; 160 KiB on gfx950: 45 KiB and 18 KiB beside the 36 KiB of staging.
+  static std::atomic<int> cu_lds{0};
+  if (!cu_lds) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev) != hipSuccess || v < 65536)
+      v = 163840;
+    cu_lds = v;
+  }
+  const int staging = 8 * 3 * kStripIn * (int)sizeof(double) + 64;
+  const int share = cu_lds.load(std::memory_order_relaxed) / (wpb == 8 ? 2 : 3) + 1024;
+  const unsigned lds_pad = share > staging ? (unsigned)(share - staging) : 0u;
   // the two waves of a SIMD keep each other in step (see the marching loop); WDPM_PRIO=0: no priorities (A/B, tests)
   static std::atomic<int> env_prio{-1};
   if (env_prio < 0) { const char *e = getenv("WDPM_PRIO"); env_prio = e ? atoi(e) : 1; }
