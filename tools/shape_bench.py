@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
 """time the stencil kernels on non-square rasters (e.g. the slabs of a multi-GPU run):
     shape_bench.py rows cols [iters] [kernels: fused,pass] [module: add|drain]
-The DEM is rounded to 1e-4 m, so the DEM-code path applies as it does to real DEMs (WDPM_DEM32=0 turns it off,
-WDPM_FILL_PERCENT overrides the waves-per-SIMD choice)."""
+The DEM is rounded to 1e-4 m, so the DEM-code path applies as it does to real DEMs (WDPM_DEM32=0 turns it off)."""
 import sys, time
 import numpy as np
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
