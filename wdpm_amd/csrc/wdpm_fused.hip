@@ -9,12 +9,11 @@
  *  - A wave64 is the unit of work; waves never synchronise with each other (no barriers; LDS is
  *    only a wave-private transpose buffer for the stores).  Lane m owns raster columns
  *    c0+3m .. c0+3m+2, so a wave covers a 192-column strip and a 64-lane row load is one
- *    contiguous 1536-byte segment.  Waves per SIMD: one for add/subtract on the fp64 DEM, two for drain
- *    (bound by instruction issue) and for add/subtract on the DEM codes below.  The two waves of a SIMD are kept
- *    in step by issue priorities that fall as a wave advances (PRIO instantiations, tall chunks: see the marching
- *    loop); with that the add kernel issues fp64 VALU instructions in ~95 % of its cycles (SQ_INSTS_VALU x 4 / SIMD
- *    over GRBM_GUI_ACTIVE / 8; 85 % before) while the memory system carries ~4.8 TB/s
- *    ("what the add kernel is bound by").
+ *    contiguous 1536-byte segment.  Waves per SIMD: two wherever chunks of 18 (add / subtract on the DEM codes) or 12 rows
+ *    (drain) fill every slot, one otherwise.  With two, a workgroup is eight waves and the two waves of a SIMD tell each other
+ *    their step through LDS: whoever is behind is served first (see the marching loop).  Chunk heights follow what each XCD
+ *    delivers (wdpm_kernels.h::XcdBalance).  Round 4's counters: fp64 VALU issue in ~89 % of the kernel's cycles, ~4.7 TB/s of
+ *    HBM traffic - between both ceilings.
  *  - The wave marches down a chunk of rows with a 7-row window held in registers (dem + water,
  *    3 columns per lane).  Each step loads 3 new rows and applies, in this order, row alignment
  *    oi=1 to rows 3n..3n+2, oi=2 to rows 3n-2..3n, oi=3 to rows 3n-4..3n-2 — a skew that respects
@@ -33,21 +32,24 @@
  *
  *  - DEM32: the static DEM can be streamed as 32-bit codes q with dem == (q + k0) / 10^e bit for bit
  *    (verified per cell at upload by the decoder used here, wdpm_stencil.h::dem32_decode): 12 bytes
- *    per lane and row in one global_load_dwordx3, 20 B of HBM traffic per cell-update instead of 24.
+ *    per lane and row in one global_load_dwordx3, 20 B of HBM traffic per cell-update instead of 24 - on the largest launches
+ *    as 16-bit offsets from one 32-bit base per 48 columns (18.1 B; wdpm_kernels.h::DemCode).
  *  - Memory operations are unconditional and fixed in number per step (prefetch by inline-asm
  *    loads one step ahead, exact s_waitcnt; stores transposed through LDS to 512-byte contiguous
- *    non-temporal writes, issued at the top of the following step).
+ *    writes, saddr-form inline asm, issued at the top of the following step).
+ *  - The neighbour step is 9 (add) / 14 (drain) VALU instructions where the depths a wave holds allow the one-instruction
+ *    clamped max(x / 8, -0.0) (wdpm_stencil.h; `deep` below), 10 / 15 otherwise.
  *
  * Results are bit-identical to the serial reference: same operands, same order, fp64, no FMA in
  * the stencil (the DEM decode uses two, on values it has been verified to reproduce exactly).
  *
  * Three kernels share the per-block arithmetic (block_update / blocks_lockstep) and the trapezoid:
- *   fused_iteration_kernel  the marching window above: rasters that fill the chip (from ~2000^2 add, ~3600^2 drain)
+ *   fused_iteration_kernel  the marching window above: rasters that fill the chip (from ~2300^2 add, ~2900^2 drain)
  *   relay_iteration_kernel  workgroups of four / eight waves, one row block per wave and row alignment, shared rows passed
  *                           through LDS: small and mid-size rasters (round 3; 482^2 add 7.3 -> 5.2 us, drain 12.1 -> 8.4)
  *   tri_iteration_kernel    one wave, nine (twelve) rows in, three (six) out, row blocks in lockstep: what is between the two,
  *                           and a small raster's last launch of a block (max diff folded in)
- * wdpm_launch_fused_rows picks by size, module and what is known about the raster (DESIGN.md §4.1c, §4.1c').
+ * wdpm_launch_fused_rows picks by size, module and what is known about the raster.
  */
 #include "wdpm_kernels.h"
 #include "wdpm_stencil.h"
@@ -662,8 +664,8 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
 
       // rows 3n-4 .. 3n-2 have now seen all nine passes.  The wave transposes each row through its
       // private LDS slice (no barrier: a wave's LDS operations complete in order) so that every
-      // store instruction writes 512 contiguous bytes, streamed past the L2 (non-temporal); the
-      // stores themselves are issued by write_staged() at the top of the next step.
+      // store instruction writes 512 contiguous bytes; the stores themselves are issued by write_staged()
+      // at the top of the next step.
       if (MD) {
         // rows 3n-4 .. 3n-2 are final: their part of the block's max-change reduction, against the snapshot
         // (which may still be owed the block's flush: applied as it is read).  Only cells of this wave's own
@@ -1320,7 +1322,8 @@ relay_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
     // bytes - as the marching kernel does.  Lane by lane a wave's three stores per row interleave at 24-byte strides, and as
     // non-temporal stores they reach the memory as partial lines: 52 MB written per 2000^2 launch for 32 MB of raster
     // (profiles/r03/add2000_pmc_summary.json; add 2000^2 28.9 -> 26.1 us, 3000^2 58.2 -> 50.8, relay_stores_ab.txt).  Lanes past
-    // the exact output range are clamped onto its last column.  store_plain: see fused_iteration_kernel.
+    // the exact output range are clamped onto its last column.  store_plain bit 0: ordinary instead of non-temporal stores (the
+    // host sets it for launches of six rounds and more: relay_stores_ab.txt).
     double *const t[3] = {&xdem[0][wave][0], &xdem[1][wave][0], &xch[0][wave][0]};
 #pragma unroll
     for (int i = 0; i < 3; i++)
@@ -1643,11 +1646,9 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
                                   hipStream_t s, TilePlan *tiles, const MaxDiffArgs *md, int leave_cus, int plain_water,
                                   XcdBalance *bal) {
   if (tiles) tiles->maintained = 0;
-  /* The gate-free variants (PLAIN, see block_update) exist for the launches between a block's first (flush on load) and last
-   * (max diff) - of the drain module, which is bound by instruction issue (+4.5 % at 8192^2, +3.8 % at 4096^2), and of the
-   * triangle kernel (+3 % at 482^2).  The marching add / subtract kernel keeps its gate: 35 of 1001 instructions per step
-   * less changed nothing at 16384^2 and 8192^2 and cost 1 % at 4096^2 (profiles/r03/plain_water_ab.txt; DESIGN.md §4.1: that
-   * launch is bound by the memory system and by instruction issue alike). */
+  /* The gate-free variants (PLAIN, see block_update) run for the launches between a block's first (flush on load) and last
+   * (max diff), every module and kernel family, whenever the water kinds allow it (drain 8192^2 +4.5 %, 482^2 +3 %, add 16384^2
+   * +1.3 % once the two waves of a SIMD ran in step: profiles/r03/plain_water_ab.txt, plain_add_prio_ab.txt). */
   const bool plain = (plain_water & WDPM_LAUNCH_PLAIN) && !signed_zero_safe && !flush && !(md && md->old);
   const int no_clamp = (plain_water & WDPM_LAUNCH_CLAMP_OK) ? 0 : 1;     /* see `deep` in the marching kernel */
   const bool fold_md = md && md->old && module != 2 && !signed_zero_safe;
