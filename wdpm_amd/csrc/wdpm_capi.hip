@@ -23,13 +23,8 @@
 
 #include "wdpm_ctx.h"
 
-/* chunk height of the iteration kernel once most tiles are dry (WDPM_SPARSE_ROWS overrides: tuning) */
-static int sparse_chunk_rows() {
-  static std::atomic<int> v{0};
-  if (!v) { const char *e = getenv("WDPM_SPARSE_ROWS"); v = e && atoi(e) >= 6 ? atoi(e) / 3 * 3 : 96; }
-  return v;
-}
-#define kSparseChunkRows sparse_chunk_rows()
+/* chunk height of the iteration kernel once most tiles are dry (24 ... 384 rows measured in round 2: profiles/r02/sparse.txt) */
+constexpr int kSparseChunkRows = 96;
 
 static thread_local char g_err[512] = "";
 
