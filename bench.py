@@ -471,6 +471,9 @@ def main():
             for key, fn in (("all", lib.dll.wdpm_timing_get), ("steady", lib.dll.wdpm_timing_get_steady), ("xch", lib.dll.wdpm_timing_get_exchange)):
                 lib.check(fn(h, C.byref(la), C.byref(ms)))
                 row[key] = (la.value, ms.value)
+            nb, wb = C.c_int32(), (C.c_double * 9)()
+            lib.check(lib.dll.wdpm_balance_info(h, C.byref(nb), wb))
+            row["balance"] = (nb.value, [float(v) for v in wb])
             per_rank.append(row)
         v = C.c_int64()
         lib.check(lib.dll.wdpm_get_option(ctx0, wdpm_amd.OPT_DEM32, C.byref(v)))
@@ -582,7 +585,7 @@ def main():
         launches, kernel_ms = solver.ctx.timing()
         steady_launches, steady_ms = solver.ctx.timing_steady()
         mine = {"all": (launches, kernel_ms), "steady": (steady_launches, steady_ms), "xch": solver.ctx.timing_exchange(),
-                "seconds": dt_mine}
+                "seconds": dt_mine, "balance": solver.ctx.balance_info()}
         per_rank = [mine]
         if world > 1:
             per_rank = [None] * world
@@ -663,6 +666,9 @@ def main():
                          "kernel_ms_per_iteration_all_launches": all_ms,
                          "frac_all_launches": ALGO_BYTES_PER_CELL_UPDATE * own_cells / (all_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if all_ms > 0 else 0.0},
         }
+        # chunk heights by XCD as rank 0 ended up with them: rebalances so far, the eight weights (which XCDs of this
+        # box are slow, and by how much) and the factor on a strip's last chunk; all 1 / 0.95 where the balance did not engage
+        out["config"]["xcd_balance"] = {"updates": per_rank[0]["balance"][0], "weights": [round(v, 4) for v in per_rank[0]["balance"][1]]}
         if ranks_used > 1:
             # what an N-GPU line needs to explain its own scaling: per rank, the stencil launches' device time per
             # iteration (HIP events on the rank's stream; `steady` = the plain instance between a block's first and last launch),
@@ -679,6 +685,7 @@ def main():
                 "refresh_us": [r["xch"][1] * 1e3 / r["xch"][0] if r["xch"][0] else None for r in per_rank],
                 "refresh_ms_total": [r["xch"][1] for r in per_rank],
                 "block_seconds": [r.get("seconds") for r in per_rank],
+                "xcd_balance_updates": [r["balance"][0] for r in per_rank],
                 "kernel_ms_min_max": [min(k_all), max(k_all)],
                 "note": "refresh_us is measured on the receiving rank's stream: it contains the wait for the sender's kernels; a refresh that "
                         "hides behind the overlapped interior launch still shows its full length here",

@@ -178,6 +178,11 @@ int wdpm_timing_get_steady(wdpm_ctx *ctx, int64_t *launches, double *ms);
  * to the kernel time, what an N-GPU run needs to explain its scaling (bench.py reports both per rank).  No counterpart in
  * the reference (one OpenCL device, WDPMCL.c:598-638). */
 int wdpm_timing_get_exchange(wdpm_ctx *ctx, int64_t *refreshes, double *ms);
+/* chunk heights that follow what each XCD delivers (no counterpart in the reference): how often the weights have been
+ * rebalanced so far, and the nine weights - relative chunk heights of the work items of XCD 0 .. 7 (logical: blockIdx % 8), mean 1, and
+ * the factor on a strip's last chunk.  All 1 (0.95) and 0 updates while the balance has not engaged (small or mostly dry rasters, WDPM_BALANCE=0).
+ * bench.py prints them: which XCDs of a box are slow, and by how much, is part of what explains a number. */
+int wdpm_balance_info(wdpm_ctx *ctx, int32_t *updates, double *weights9);
 /* what this library was built from: "kernels=<first 16 hex digits of the sha256 of the kernel sources> arch=... sched=..." - bench.py
  * quotes counter evidence collected on another run (profiles/traffic.json) only for a library that says the same */
 const char *wdpm_build_info(void);

@@ -93,6 +93,32 @@ def test_add_at_full_size_equals_the_reference(hip, golden, name, variant):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,blocks", [(4096, (6, 14, 9)), (8192, (5, 9))])
+def test_chunk_heights_by_xcd_engage_and_change_nothing(hip, monkeypatch, n, blocks):
+    """round 4: from the second block of a mostly wet raster on, the marching kernel's chunk heights follow what each XCD delivers
+    (wdpm_kernels.h::XcdBalance: weights measured on the device, a table of row boundaries per strip).  The balance must ENGAGE on
+    rasters of this size (wdpm_balance_info: at least one rebalance, weights around 1) and must not change a bit of the result:
+    the same blocks with WDPM_BALANCE=0 (read when a context is made)."""
+    bd, bw = inputs(hip, n)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("WDPM_BALANCE", mode)
+        with hip.context(module="add", nrows=n, ncols=n, missingvalue=MISS) as c:
+            c.upload(bd, bw)
+            mds = [c.run_block(k, THRES) for k in blocks]
+            updates, weights = c.balance_info()
+            out[mode] = (sha(c.download_water()), mds, updates, weights)
+    assert out["1"][:2] == out["0"][:2]
+    assert out["0"][2] == 0 and out["0"][3] == [1.0] * 8 + [0.95]
+    updates, weights = out["1"][2:]
+    assert updates >= 1, "the balance never engaged"
+    assert all(0.7 <= w <= 1.4 for w in weights[:8]) and abs(sum(weights[:8]) / 8 - 1.0) < 0.02 and 0.75 <= weights[8] <= 1.2, weights
+    os.makedirs(os.path.join(os.path.dirname(GOLDEN), "..", "gpurun_out"), exist_ok=True)
+    with open(os.path.join(os.path.dirname(GOLDEN), "..", "gpurun_out", "xcd_weights.txt"), "a") as f:
+        f.write(f"{n}x{n} after blocks {blocks}: {updates} rebalances, weights {[round(w, 3) for w in weights]}\n")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("devices,k", [([0, 0, 0, 0], 1), ([0] * 8, 2)])
 def test_row_blocks_at_16384_equal_the_reference(hip, golden, devices, k):
     """config 4's decomposition (here: the slabs of one GPU, one host thread each) against the REFERENCE's

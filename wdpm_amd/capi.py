@@ -101,6 +101,7 @@ SYMBOLS = {
     "wdpm_timing_get_steady": (C.c_int, [_vp, C.POINTER(C.c_int64), _dp]),
     "wdpm_timing_get_exchange": (C.c_int, [_vp, C.POINTER(C.c_int64), _dp]),
     "wdpm_build_info": (C.c_char_p, []),
+    "wdpm_balance_info": (C.c_int, [_vp, C.POINTER(C.c_int32), _dp]),
     "wdpm_copy_rows": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, C.c_int32]),
     "wdpm_set_last_error": (None, [C.c_char_p]),
     "wdpm_enable_peer_access": (C.c_int, [_vp, _vp]),
@@ -399,6 +400,12 @@ class Context:
         n, ms = C.c_int64(), C.c_double()
         self.lib.check(self.lib.dll.wdpm_timing_get_steady(self._h, C.byref(n), C.byref(ms)))
         return n.value, ms.value
+
+    def balance_info(self):
+        """(rebalances so far, [eight per-XCD chunk-height weights, the factor on a strip's last chunk])"""
+        n, w = C.c_int32(), (C.c_double * 9)()
+        self.lib.check(self.lib.dll.wdpm_balance_info(self._h, C.byref(n), w))
+        return n.value, [float(v) for v in w]
 
     def timing_exchange(self):
         """(halo refreshes into this context, ms on its stream from queueing a transfer to its rows' arrival) since the last reset"""

@@ -1154,6 +1154,19 @@ int wdpm_timing_reset(wdpm_ctx *x) {
   return 0;
 }
 
+int wdpm_balance_info(wdpm_ctx *x, int32_t *updates, double *weights9) {
+  if (updates) *updates = x->bal.mode ? x->bal.updates : 0;
+  if (!weights9) return 0;
+  for (int i = 0; i < 9; i++) weights9[i] = i < 8 ? 1.0 : 0.95;
+  if (!x->bal.mode || !x->bal.weight) return 0;
+  if (bind(x)) return 1;
+  float w[9];
+  HIP_TRY(hipMemcpyAsync(w, x->bal.weight, sizeof w, hipMemcpyDeviceToHost, x->stream));
+  if (wdpm_stream_sync(x, x->stream)) return 1;
+  for (int i = 0; i < 9; i++) weights9[i] = (double)w[i];
+  return 0;
+}
+
 int wdpm_timing_get_exchange(wdpm_ctx *x, int64_t *refreshes, double *ms) {
   if (bind(x)) return 1;
   if (fold_timing(x)) return 1;
