@@ -212,7 +212,7 @@ def oracle_baseline(samples):
     return out
 
 
-def cpu_baseline(n=16384, full=False):
+def cpu_baseline(n=16384, full=False, quick=False):
     """The reference's own serial code if its prebuilt library is present (kind "reference"), else the
     CPU oracle (bit-equal port of it, kind "port"), timed on ONE host core (the reference's serial path is
     single-threaded) on bounded samples of the same workload.  The headline `value` is on the metric's own
@@ -223,6 +223,8 @@ def cpu_baseline(n=16384, full=False):
     # the headline sample: the bench's own raster size, as many iterations as take about 13 s (never fewer than two)
     head_iters = 10 if full and n >= 16384 else max(2, min(1000, int(round(5.5e8 / (float(n) * n)))))
     samples = [(n, head_iters), (4096, 24), (1024, 1000)]
+    if quick:        # tests of the line's shape only (--cpu-baseline-quick): seconds instead of a minute, not a baseline anybody should quote
+        samples = [(n, 3), (4096, 1), (1024, 10)]
     kind, res = "reference", reference_baseline(samples)
     if res is None:
         kind, res = "port", oracle_baseline(samples)
@@ -231,6 +233,7 @@ def cpu_baseline(n=16384, full=False):
             "oracle/wdpm_oracle.c")
     return {"value": head["value"], "unit": "cell-updates/s", "cores": 1, "kind": kind, "cpu_model": cpu_model(),
             "host_cores": os.cpu_count(),
+            **({"quick": "shape test only: a few iterations per sample"} if quick else {}),
             "sample": f"{what}, synthetic {head['size']}x{head['size']} all-wet add 100 mm (the metric's own raster), "
                       f"{head['iterations']} iterations after one untimed, {head['seconds']:.1f} s, one thread (the reference's serial path has no other)",
             "samples": res}
@@ -356,6 +359,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-full", action="store_true",
                     help="also time SURVEY §8d's 16384^2 x 10 iterations on the host (about a minute) and make it the headline")
+    ap.add_argument("--cpu-baseline-quick", action="store_true",
+                    help="tests only: a few iterations per CPU sample (the line's shape, not a baseline to quote)")
     args = ap.parse_args()
 
     launched = "WORLD_SIZE" in os.environ
@@ -694,7 +699,7 @@ def main():
             out["degraded"] = True
             out["degraded_reason"] = degraded
         if not args.no_cpu_baseline and ranks_used == 1:   # rank 0 at N=1 only
-            out["cpu_baseline"] = cpu_baseline(n, full=args.cpu_baseline_full)
+            out["cpu_baseline"] = cpu_baseline(n, full=args.cpu_baseline_full, quick=args.cpu_baseline_quick)
         print(json.dumps(out), flush=True)
     if degraded:
         # a helper thread may still sit inside the RCCL call that never came back: leave without running anybody's destructors

@@ -24,7 +24,7 @@ def run_bench(*args):
 
 @gpu
 def test_bench_line_has_the_contract_fields():
-    d = run_bench("--size", "1024", "--steps", "7", "--warmup", "2")
+    d = run_bench("--size", "1024", "--steps", "7", "--warmup", "2", "--cpu-baseline-quick")
     assert d["metric"] == "cell-updates/sec on Add module, 1024x1024 DEM" and d["unit"] == "cell-updates/s"
     assert d["n_gpus"] == 1 and d["steps"] == 7 and d["warmup"] == 2
     assert d["higher_is_better"] is True and d["scaling"] == "strong" and d["vs_baseline"] is None
@@ -43,10 +43,25 @@ def test_bench_line_has_the_contract_fields():
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["value"] > 0 and c["unit"] == "cell-updates/s"
     assert "iterations" in c["sample"] and c["cpu_model"] and c["host_cores"] >= 1
-    # the headline sample is on the bench's own raster (16384^2 x 2 for the default command, x 10 behind --cpu-baseline-full;
-    # here 1024^2 x 525: about 13 s), SURVEY §8d's 4096^2 x 24 and 1024^2 x 1000 beside it
-    assert [(x["size"], x["iterations"]) for x in c["samples"]] == [(1024, 525), (4096, 24), (1024, 1000)] and c["value"] == c["samples"][0]["value"]
+    # the headline sample is on the bench's own raster (16384^2 x 2 for the default command, x 10 behind --cpu-baseline-full),
+    # SURVEY §8d's 4096^2 and 1024^2 samples beside it; --cpu-baseline-quick (this test) runs the same three for a few iterations
+    assert [x["size"] for x in c["samples"]] == [1024, 4096, 1024] and c["value"] == c["samples"][0]["value"] and "quick" in c
     assert "the metric's own raster" in c["sample"]
+
+
+def test_cpu_baseline_samples_of_the_default_command():
+    """which samples the un-flagged bench times (no GPU, nothing is run): the metric's own raster first"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_samples", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    seen = []
+    mod.reference_baseline = lambda samples: (seen.append(list(samples)) or [{"size": n, "iterations": k, "seconds": 1.0, "value": 1.0} for n, k in samples])
+    assert mod.cpu_baseline(16384)["samples"][0]["size"] == 16384 and seen[-1] == [(16384, 2), (4096, 24), (1024, 1000)]
+    mod.cpu_baseline(16384, full=True)
+    assert seen[-1][0] == (16384, 10)
+    mod.cpu_baseline(1024)
+    assert seen[-1][0] == (1024, 525)
 
 
 def test_counter_evidence_is_quoted_for_the_headline_configuration_and_build():
