@@ -34,6 +34,9 @@ def test_bench_line_has_the_contract_fields():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0
     assert list(r)[:2] == ["bound", "job_frac"] and 0 < r["job_frac"] <= r["frac_all_launches"] * 1.001
+    # a short run also reports the same K iterations once more, after the timed block and beside it (the card's clocks have come up by then)
+    nb = r["next_block"]
+    assert 0 < nb["job_frac"] < 1 and nb["ms_per_step"] > 0 and nb["kernel_ms_per_iteration"] > 0 and "not `value`" in nb["what"]
     # counter evidence (HBM bytes, VALU issue share) is only quoted for the configuration it was measured on
     assert r["traffic"] is None and r["hbm_real_frac"] is None and r["valu_issue_frac"] is None and r["counters_source"] is None
     # the dominant kernel is the plain instance (launches 2 .. K-1); the all-launch average (flush-on-load first launch,
