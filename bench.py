@@ -596,12 +596,18 @@ def main():
         if world > 1:
             per_rank = [None] * world
             dist.all_gather_object(per_rank, mine)
-        # The same K steps ONCE MORE, straight on, outside the contract's timed region and reported beside it, never as `value`:
-        # an MI355X that has idled for 5 ms runs this kernel 10 - 35 % slower and takes ~30 iterations of it to come back
-        # (profiles/r04/first_iterations2.txt: no sleep, no copy and no other kernel but this one shortens that), so
-        # `--warmup 5 --steps 20` times the ramp itself; the block after it shows the same box at the clocks the reference's
-        # 1000-iteration blocks run at.  Short runs of the add module only (a long one is past the ramp by itself).
+        # The same K steps ONCE MORE, outside the contract's timed region and reported beside it, never as `value`: an MI355X whose
+        # compute units have idled for 5 ms runs this kernel 10 - 35 % slower and takes ~30 ms of THIS kernel to come back
+        # (profiles/r04/first_iterations2.txt: no sleep, copy or other kernel shortens that), so `--warmup 5 --steps 20` times
+        # the ramp itself - and at N = 8, where its 25 iterations last 4 ms, the slowest part of it.  After the timed block:
+        # untimed iterations until 50 ms have gone by since the warm-up began (the same number on every rank), then K timed
+        # ones - the same box at the clocks the reference's 1000-iteration blocks run at.  Short add runs only (a long one is
+        # past the ramp by itself).
         if args.module == "add" and args.steps <= 200 and not degraded:
+            per_step = dt / max(args.steps, 1)
+            more = int(min(4000, max(0.0, 0.050 - dt - args.warmup * per_step) / per_step)) if per_step > 0 else 0
+            if more > 0:
+                solver.run_block(more, THRES)
             torch.cuda.synchronize()
             if world > 1:
                 dist.barrier()
@@ -611,7 +617,7 @@ def main():
             solver.run_block(args.steps, THRES)
             torch.cuda.synchronize()
             dt2 = dist_max(time.perf_counter() - t1)
-            again = (dt2, solver.ctx.timing_steady())
+            again = (dt2, solver.ctx.timing_steady(), more)
         dem32 = bool(solver.ctx.get_option(wdpm_amd.OPT_DEM32)) and args.module == "add"
         dem16 = dem32 and solver.ctx.get_option(wdpm_amd.capi.OPT_DEM16) == 1     # (2: available, but this slab is too small for them to pay)
         own_rows0 = solver.slab.own_hi - solver.slab.own_lo + 1 if world > 1 else n
@@ -689,10 +695,12 @@ def main():
                          "frac_all_launches": ALGO_BYTES_PER_CELL_UPDATE * own_cells / (all_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if all_ms > 0 else 0.0},
         }
         if again is not None:
-            dt2, (l2, ms2) = again
+            dt2, (l2, ms2), more = again
             out["roofline"]["next_block"] = {
-                "what": f"the same {args.steps} iterations once more, straight after the timed block (not `value`: the contract's block is the "
-                        "one above); the card leaves its idle clocks over ~30 iterations of this kernel, profiles/r04/first_iterations2.txt",
+                "what": f"the same {args.steps} iterations once more, after the timed block and {more} further untimed ones (not `value`: the "
+                        "contract's block is the one above); the card leaves its idle clocks over ~30 ms of this kernel and of nothing "
+                        "else, profiles/r04/first_iterations2.txt",
+                "untimed_iterations_before": more,
                 "ms_per_step": dt2 * 1e3 / args.steps,
                 "job_frac": cells * args.steps / dt2 * ALGO_BYTES_PER_CELL_UPDATE / 1e9 / (HBM_PEAK_GBS * ranks_used),
                 "kernel_ms_per_iteration": ms2 / l2 if l2 else None,

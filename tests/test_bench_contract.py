@@ -37,6 +37,7 @@ def test_bench_line_has_the_contract_fields():
     # a short run also reports the same K iterations once more, after the timed block and beside it (the card's clocks have come up by then)
     nb = r["next_block"]
     assert 0 < nb["job_frac"] < 1 and nb["ms_per_step"] > 0 and nb["kernel_ms_per_iteration"] > 0 and "not `value`" in nb["what"]
+    assert nb["untimed_iterations_before"] > 100        # 1024^2: microseconds per iteration, 50 ms of ramp
     # counter evidence (HBM bytes, VALU issue share) is only quoted for the configuration it was measured on
     assert r["traffic"] is None and r["hbm_real_frac"] is None and r["valu_issue_frac"] is None and r["counters_source"] is None
     # the dominant kernel is the plain instance (launches 2 .. K-1); the all-launch average (flush-on-load first launch,
