@@ -483,7 +483,7 @@ def main():
             per_rank.append(row)
         v = C.c_int64()
         lib.check(lib.dll.wdpm_get_option(ctx0, wdpm_amd.OPT_DEM32, C.byref(v)))
-        dem32 = bool(v.value) and args.module == "add"
+        dem32 = bool(v.value)
         lib.check(lib.dll.wdpm_get_option(ctx0, wdpm_amd.capi.OPT_DEM16, C.byref(v)))
         dem16 = dem32 and v.value == 1
         sl = wdpm_amd.capi.SlabStruct()
@@ -618,7 +618,7 @@ def main():
             torch.cuda.synchronize()
             dt2 = dist_max(time.perf_counter() - t1)
             again = (dt2, solver.ctx.timing_steady(), more)
-        dem32 = bool(solver.ctx.get_option(wdpm_amd.OPT_DEM32)) and args.module == "add"
+        dem32 = bool(solver.ctx.get_option(wdpm_amd.OPT_DEM32))      # (drain too, from round 4: launches of two waves per SIMD)
         dem16 = dem32 and solver.ctx.get_option(wdpm_amd.capi.OPT_DEM16) == 1     # (2: available, but this slab is too small for them to pay)
         own_rows0 = solver.slab.own_hi - solver.slab.own_lo + 1 if world > 1 else n
         decomposition = f"row-block x{world}, one process per GPU" if world > 1 else "single GPU"

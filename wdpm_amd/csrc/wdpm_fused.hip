@@ -1667,8 +1667,7 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
   int nstrips = 1;
   if (g.ncp > kStripIn - kHaloR) nstrips = (g.ncp - (kStripIn - kHaloR) + kStripOut - 1) / kStripOut + 1;
   const bool fast = !signed_zero_safe;
-  // add / subtract with an encodable DEM: 20 B per cell-update instead of 24 (drain is latency-bound,
-  // not HBM-bound, and keeps the fp64 DEM: the decode would only add instructions)
+  // add / subtract with an encodable DEM: 20 B per cell-update instead of 24 (drain: see big_drain below)
   // ... and only pays on launches big enough for two waves per SIMD (see below): at one wave per SIMD
   // the wave's own latency chain is the limit and the nine decodes per step cost 3-5 % (size sweep in
   // profiles/r01: 512^2 - 3072^2 slower with codes, 4096^2 and up 5-12 % faster).
@@ -1678,9 +1677,14 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
   // (profiles/r04/tall_rows_sweep.txt).
   constexpr long long tall_add = 18, tall_drain = 12;
   const bool big = (long long)(out_last - A0 + 1) * nstrips >= (long long)tall_add * resident_waves<0, false>();
-  const bool dem32 = fast && module != 2 && code.q != nullptr && (big || code.force);
+  // Drain with the codes (round 4, late): "latency-bound, the decode would only add instructions" was round 1's reading of a kernel
+  // at one wave per SIMD; at two, and with the card at its power cap whatever the kernel does, four bytes per
+  // cell-update less are worth more than the nine decodes of a step - on launches that fill every slot at two waves per SIMD.
+  const bool big_drain = module == 2 && fast &&
+                         (long long)(out_last - A0 + 1) * nstrips >= (long long)tall_drain * resident_waves<2, false, 1>();
+  const bool dem32 = fast && code.q != nullptr && ((module == 2 ? big_drain : big) || code.force);
   bool two_per_simd = false;      /* every slot filled: two waves per SIMD, workgroups of eight waves (one per CU) */
-  int slots = module == 2 ? (fast ? resident_waves<2, false>() : resident_waves<2, true>())
+  int slots = module == 2 ? (!fast ? resident_waves<2, true>() : dem32 ? resident_waves<2, false, 1>() : resident_waves<2, false>())
               : dem32     ? resident_waves<0, false, 1>()
               : fast      ? resident_waves<0, false>()
                           : resident_waves<0, true>();
@@ -1792,14 +1796,19 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
 #define WDPM_LAUNCH_ADD(D32) do { if (fold_md) { if (flush) WDPM_LAUNCH(0, false, D32, true, true); else WDPM_LAUNCH(0, false, D32, false, true); } \
                                   else if (plain) WDPM_LAUNCH(0, false, D32, false, false, true);                                                   \
                                   else if (flush) WDPM_LAUNCH(0, false, D32, true, false); else WDPM_LAUNCH(0, false, D32, false, false); } while (0)
-  if (module == 2 && !fast) WDPM_LAUNCH(2, true, 0, false, false);
-  else if (module == 2 && plain) WDPM_LAUNCH(2, false, 0, false, false, true);
-  else if (module == 2) { if (flush) WDPM_LAUNCH(2, false, 0, true, false); else WDPM_LAUNCH(2, false, 0, false, false); }
-  else if (!fast) WDPM_LAUNCH(0, true, 0, false, false);
+#define WDPM_LAUNCH_DRAIN(D32) do { if (plain) WDPM_LAUNCH(2, false, D32, false, false, true);                                                      \
+                                    else if (flush) WDPM_LAUNCH(2, false, D32, true, false); else WDPM_LAUNCH(2, false, D32, false, false); } while (0)
   // the codes as 16-bit offsets (18.1 B of HBM traffic per cell-update) on launches of 10^8 cells and more: wdpm_kernels.h::wdpm_dem16_pays
-  else if (dem32 && code.h != nullptr && wdpm_dem16_pays((long long)wrows * g.ncp, code.force)) WDPM_LAUNCH_ADD(2);
+  const bool dem16 = dem32 && code.h != nullptr && wdpm_dem16_pays((long long)wrows * g.ncp, code.force);
+  if (module == 2 && !fast) WDPM_LAUNCH(2, true, 0, false, false);
+  else if (module == 2 && dem16) WDPM_LAUNCH_DRAIN(2);
+  else if (module == 2 && dem32) WDPM_LAUNCH_DRAIN(1);
+  else if (module == 2) WDPM_LAUNCH_DRAIN(0);
+  else if (!fast) WDPM_LAUNCH(0, true, 0, false, false);
+  else if (dem16) WDPM_LAUNCH_ADD(2);
   else if (dem32) WDPM_LAUNCH_ADD(1);
   else WDPM_LAUNCH_ADD(0);
+#undef WDPM_LAUNCH_DRAIN
 #undef WDPM_LAUNCH_ADD
 #undef WDPM_LAUNCH
   return hipGetLastError();
