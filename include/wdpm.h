@@ -331,7 +331,8 @@ int  wdpm_group_enqueue_stats(wdpm_group *grp, double *seconds, double *exchange
  *   has verified, cell by cell and bit for bit, that the DEM is k / 10^e with 32-bit k (DEMs read
  *   from decimal text are); results are identical either way.  Setting 0 forces the fp64 DEM,
  *   setting 1 is honoured only for a DEM that passed the check; the kernel then uses the codes on
- *   launches large enough for them to pay (>= 4096^2 or so), setting 2 on launches of any size.  WDPM_DEM32=0 in the environment
+ *   launches large enough for them to pay (add / subtract >= 4096^2 or so; drain, from round 4, on launches of two waves per SIMD),
+ *   setting 2 on launches of any size.  WDPM_DEM32=0 in the environment
  *   disables the encoding altogether, WDPM_DEM32=2 makes 2 the default.  The CPU restatement reports 0.
  * WDPM_OPT_DEM16 (get/set; round 4): 1 = the marching kernel streams those codes as 16-bit offsets from one 32-bit base per 48
  *   columns of a row (2.08 B per cell: 18.1 B of HBM traffic per cell-update) - an exact integer identity with the verified 32-bit
