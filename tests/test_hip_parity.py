@@ -81,7 +81,7 @@ def test_random_rasters_match_oracle(hip, oracle, module, kernel, R, C, chunk):
 
 
 @pytest.mark.parametrize("dem32", [0, 1])
-@pytest.mark.parametrize("module", ["add", "subtract"])
+@pytest.mark.parametrize("module", ["add", "subtract", "drain"])      # (drain streams the codes from round 4 on)
 @pytest.mark.parametrize("R,C,chunk", [(38, 398, 12), (100, 700, 0), (301, 170, 48), (64, 1100, 30), (5, 175, 3), (1, 1, 0)])
 def test_dem_codes_on_and_off(hip, oracle, module, R, C, chunk, dem32):
     """the one-iteration kernel with the DEM streamed as verified 32-bit codes (WDPM_OPT_DEM32) and with
@@ -90,7 +90,7 @@ def test_dem_codes_on_and_off(hip, oracle, module, R, C, chunk, dem32):
                          kernel=wdpm_amd.KERNEL_FUSED, chunk=chunk, dem32=dem32)
 
 
-@pytest.mark.parametrize("module", ["add", "subtract"])
+@pytest.mark.parametrize("module", ["add", "subtract", "drain"])
 @pytest.mark.parametrize("R,C,chunk", [(38, 398, 12), (100, 700, 0), (301, 170, 48), (64, 1100, 30), (5, 175, 3), (1, 1, 0)])
 def test_dem_codes_as_16_bit_offsets_on_and_off(hip, oracle, module, R, C, chunk):
     """round 4: the verified 32-bit codes once more as 16-bit offsets from one base per 48 columns of a row (18.1 B of HBM traffic
@@ -106,10 +106,18 @@ def test_dem_codes_as_16_bit_offsets_on_and_off(hip, oracle, module, R, C, chunk
     water = np.where(dem > miss, np.where(rng.random((R, C)) < 0.3, 0.0, 0.3 * rng.random((R, C))), 0.0)
     bd, bw = pad(dem, water, miss)
     kw = dict(module=module, nrows=R, ncols=C, missingvalue=miss)
+    td0 = 0.0
+    if module == "drain":
+        if not (dem > miss).any():
+            pytest.skip("no valid cell: no outlet")
+        dr, dc = find_drain(bd)
+        td0 = max(bw[dr, dc], 0.0)
+        kw.update(drainrow=dr, draincol=dc)
     out = {}
     for mode in ("fp64", "codes32", "codes16"):
         with hip.context(kernel=wdpm_amd.KERNEL_FUSED, chunk_rows=chunk, **kw) as g:
             g.upload(bd, bw)
+            g.totaldrain = td0
             can16 = bool((dem > miss).any()) and os.environ.get("WDPM_DEM16", "1") != "0"      # (the forced-variant suites switch it off)
             small = 1 if os.environ.get("WDPM_DEM32") == "2" else 2                     # 2: available, but a raster this small keeps the 32-bit codes
             assert g.get_option(wdpm_amd.capi.OPT_DEM16) == (small if can16 else 0)       # (1 under the forced-variant suites' WDPM_DEM32=2)
@@ -118,13 +126,14 @@ def test_dem_codes_as_16_bit_offsets_on_and_off(hip, oracle, module, R, C, chunk
             assert g.get_option(wdpm_amd.capi.OPT_DEM16) == int(mode == "codes16" and can16)
             g.iterate(7)
             md = g.run_block(5, 1e-5)
-            out[mode] = (g.download_water(), md)
+            out[mode] = (g.download_water(), md, g.totaldrain)
     with oracle.context(**kw) as o:
         o.upload(bd, bw)
+        o.totaldrain = td0
         o.iterate(7)
-        want = (o.run_block(5, 1e-5), o.download_water())
-    for mode, (w, md) in out.items():
-        assert n_bit_diff(w, want[1]) == 0 and md == want[0], mode
+        want = (o.run_block(5, 1e-5), o.download_water(), o.totaldrain)
+    for mode, (w, md, td) in out.items():
+        assert n_bit_diff(w, want[1]) == 0 and md == want[0] and td == want[2], mode
 
 
 def test_16_bit_offsets_are_refused_where_the_relief_is_too_steep(hip, oracle):
