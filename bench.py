@@ -603,7 +603,7 @@ def main():
         # untimed iterations until 50 ms have gone by since the warm-up began (the same number on every rank), then K timed
         # ones - the same box at the clocks the reference's 1000-iteration blocks run at.  Short add runs only (a long one is
         # past the ramp by itself).
-        if args.module == "add" and args.steps <= 200 and not degraded:
+        if args.module == "add" and 1 <= args.steps <= 200 and not degraded:
             per_step = dt / max(args.steps, 1)
             more = int(min(4000, max(0.0, 0.050 - dt - args.warmup * per_step) / per_step)) if per_step > 0 else 0
             if more > 0:
