@@ -19,7 +19,12 @@ reference executable, serial path cpu=0), and writes DATA only:
                       4096^2 add x20, 16384^2 add x2, 8192^2 add x3 then drain x5 - sha256 of the padded water
                       raster, an 8-byte hash of every row, sampled rows, max diff and totaldrain
 
-    python tests/golden/make_golden.py [full]      ("full": only full_size.npz)
+                      ... and (round 5) the SETTLED states: 4096^2 add x1000 and x2000 (two blocks, the flush between them),
+                      16384^2 add x100 (x300, x1000), 8192^2 add x1000 then ONE drain block seen after 100 and 1000
+
+    python tests/golden/make_golden.py [full]      ("full": only full_size.npz's early-state entries)
+    python tests/golden/make_golden.py settled cfg3|cfg4|cfg5|cfg4long   (one process each, minutes to hours of a core)
+    python tests/golden/make_golden.py merge       (fold the settled parts into full_size.npz)
 """
 import ctypes as C
 import gzip
@@ -332,9 +337,143 @@ def make_full_size(ref):
     np.savez_compressed(os.path.join(HERE, "full_size.npz"), **out)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# SETTLED states at full size (round 5).  full_size.npz's first entries are 2-20 iterations from a uniform sheet;
+# these are the BASELINE configurations as SURVEY 8d words them: config 3 = one 1000-iteration block at 4096^2
+# (and a second block behind its threshold flush), config 4 = 16384^2 over 100 (and, hours of one core, 1000)
+# iterations, config 5 = drain at 8192^2 from "that raster's add-100-mm state after 1000 iterations".  Each case is
+# a process of its own (`settled CASE`), writes a part file next to this script's output and `merge` folds the
+# parts into full_size.npz.  Reference lines followed: WDPMCL.c:1055-1125 (block), :1239-1254 (max diff).
+SETTLED_CASES = ("cfg3", "cfg4", "cfg5", "cfg4long")
+
+
+def _max_diff(w, w0, bd, missing):
+    """WDPMCL.c:1239-1254, in slabs of rows so that a 16384^2 raster needs no third full-size temporary."""
+    md = float(abs(w[0, 0] - w0[0, 0]))
+    for r in range(0, w.shape[0], 1024):
+        d = np.abs(w[r:r + 1024] - w0[r:r + 1024])[bd[r:r + 1024] > missing]
+        if d.size and float(d.max()) > md:
+            md = float(d.max())
+    return md
+
+
+def _seq_sum(w, bd, missing):
+    """final_vol's row-major sequential sum (WDPMCL.c:1262-1267) without the cell area"""
+    acc = 0.0
+    for r in range(w.shape[0]):
+        v = w[r][bd[r] > missing]
+        if v.size:
+            acc = float(np.add.accumulate(np.concatenate(([acc], v)))[-1])
+    return acc
+
+
+def make_settled(ref, case):
+    import time
+    sys.path.insert(0, ROOT)
+    import wdpm_amd
+    gen = wdpm_amd.load(os.path.join(ROOT, "oracle", "_build", "libwdpm_oracle.so"))
+    missing, thres = -99999.0, 0.005 / 1000
+    out, index = {}, []
+    part = os.path.join(HERE, f"_settled_{case}.npz")
+
+    def record(name, n, module, w, w_start, bd, td, secs, every, **extra):
+        out[name + "_rowhash"] = row_hashes(w)
+        out[name + "_rows"] = w[::every].copy()
+        index.append(dict(name=name, n=n, module=module, sha256=sha(w), max_diff=_max_diff(w, w_start, bd, missing),
+                          totaldrain=td, sample_every=every, ref_seconds=round(secs, 1),
+                          wet_cells=int(np.count_nonzero(w > 0)), deepest=float(w.max()), **extra))
+        print(name, index[-1], flush=True)
+        out["index_json"] = np.frombuffer(json.dumps(index).encode(), dtype=np.uint8)
+        np.savez_compressed(part, **out)                            # after every record: a killed run keeps its work
+
+    def start(n):
+        dem = gen.synth_dem(n, n)
+        bd, bw = pad(dem, np.full((n, n), 0.1), missing)            # add 100 mm, rof 1.0 on an empty water raster
+        bw[bw < thres] = 0
+        return bd, bw
+
+    t = time.perf_counter()
+    if case == "cfg3":
+        n = 4096
+        bd, bw = start(n)
+        ref.ref_setup(n, n, missing, bd.ctypes.data, bw.ctypes.data, 0.0, 0, 0)
+        ref.ref_iterate(ADD, 1000)
+        w1 = ref_water(ref, bd.shape)
+        record("cfg3_add_4096_i1000", n, ADD, w1, bw, bd, 0.0, time.perf_counter() - t, 512, add_iters=1000, blocks=[1000])
+        flushed = int(np.count_nonzero((w1 < thres) & (w1 != 0)))
+        w1[w1 < thres] = 0                                          # second block: :1055-1065 now does something
+        ref.ref_setup(n, n, missing, bd.ctypes.data, w1.ctypes.data, 0.0, 0, 0)
+        ref.ref_iterate(ADD, 1000)
+        w2 = ref_water(ref, bd.shape)
+        record("cfg3_add_4096_b2_i2000", n, ADD, w2, w1, bd, 0.0, time.perf_counter() - t, 512, add_iters=2000,
+               blocks=[1000, 1000], flushed_before_block2=flushed)
+    elif case in ("cfg4", "cfg4long"):
+        n = 16384
+        bd, bw = start(n)
+        ref.ref_setup(n, n, missing, bd.ctypes.data, bw.ctypes.data, 0.0, 0, 0)
+        done = 0
+        for upto in ((100,) if case == "cfg4" else (300, 1000)):
+            ref.ref_iterate(ADD, upto - done)
+            done = upto
+            w = ref_water(ref, bd.shape)
+            record(f"cfg4_add_16384_i{upto}", n, ADD, w, bw, bd, 0.0, time.perf_counter() - t, 4096, add_iters=upto,
+                   blocks=[upto])
+            del w
+    elif case == "cfg5":
+        n = 8192
+        bd, bw = start(n)
+        ref.ref_setup(n, n, missing, bd.ctypes.data, bw.ctypes.data, 0.0, 0, 0)
+        ref.ref_iterate(ADD, 1000)
+        w = ref_water(ref, bd.shape)
+        record("cfg5_add_8192_i1000", n, ADD, w, bw, bd, 0.0, time.perf_counter() - t, 2048, add_iters=1000, blocks=[1000])
+        k = int(np.argmin(np.where(bd > 0, bd, np.inf)))            # WDPMCL.c:1005-1017 (first row-major minimum)
+        dr, dc = k // (n + 2), k % (n + 2)
+        td0 = max(float(w[dr, dc]), 0.0)                            # :1029
+        flushed = int(np.count_nonzero((w < thres) & (w != 0)))
+        w[w < thres] = 0
+        ref.ref_setup(n, n, missing, bd.ctypes.data, w.ctypes.data, td0, dr, dc)
+        done = 0
+        for upto in (100, 1000):                                    # ONE drain block, looked at after 100 and 1000
+            ref.ref_iterate(DRAIN, upto - done)
+            done = upto
+            w2 = ref_water(ref, bd.shape)
+            record(f"cfg5_drain_8192_a1000_d{upto}", n, DRAIN, w2, w, bd, ref.ref_get_totaldrain(),
+                   time.perf_counter() - t, 2048, add_iters=1000, drain_iters=upto, drainrow=dr, draincol=dc, td0=td0,
+                   flushed_before_drain=flushed, volume_sum=_seq_sum(w2, bd, missing))
+            del w2
+    else:
+        sys.exit(f"unknown case {case}; one of {SETTLED_CASES}")
+
+
+def merge_settled():
+    """fold the parts written by `settled CASE` into full_size.npz (entries of the same name are replaced)"""
+    path = os.path.join(HERE, "full_size.npz")
+    z = np.load(path)
+    out = {k: z[k] for k in z.files if k != "index_json"}
+    index = json.loads(bytes(z["index_json"]).decode())
+    for case in SETTLED_CASES:
+        part = os.path.join(HERE, f"_settled_{case}.npz")
+        if not os.path.exists(part):
+            continue
+        p = np.load(part)
+        new = json.loads(bytes(p["index_json"]).decode())
+        names = {m["name"] for m in new}
+        index = [m for m in index if m["name"] not in names] + new
+        out.update({k: p[k] for k in p.files if k != "index_json"})
+        print("merged", case, sorted(names))
+    out["index_json"] = np.frombuffer(json.dumps(index).encode(), dtype=np.uint8)
+    np.savez_compressed(path, **out)
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "full":
         make_full_size(load_ref())
+        return
+    if len(sys.argv) > 2 and sys.argv[1] == "settled":
+        make_settled(load_ref(), sys.argv[2])
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "merge":
+        merge_settled()
         return
     if not os.path.exists(REF_SO):
         sys.exit("build oracle/_ref first: make -C oracle ref")
