@@ -480,6 +480,9 @@ def main():
             nb, wb = C.c_int32(), (C.c_double * 9)()
             lib.check(lib.dll.wdpm_balance_info(h, C.byref(nb), wb))
             row["balance"] = (nb.value, [float(v) for v in wb])
+            od, bus = C.c_int32(), C.create_string_buffer(32)
+            lib.check(lib.dll.wdpm_device_info(h, C.byref(od), bus, 32))
+            row["device"], row["pid"] = (od.value, bus.value.decode()), os.getpid()
             per_rank.append(row)
         v = C.c_int64()
         lib.check(lib.dll.wdpm_get_option(ctx0, wdpm_amd.OPT_DEM32, C.byref(v)))
@@ -591,7 +594,7 @@ def main():
         launches, kernel_ms = solver.ctx.timing()
         steady_launches, steady_ms = solver.ctx.timing_steady()
         mine = {"all": (launches, kernel_ms), "steady": (steady_launches, steady_ms), "xch": solver.ctx.timing_exchange(),
-                "seconds": dt_mine, "balance": solver.ctx.balance_info()}
+                "seconds": dt_mine, "balance": solver.ctx.balance_info(), "device": solver.ctx.device_info(), "pid": os.getpid()}
         per_rank = [mine]
         if world > 1:
             per_rank = [None] * world
@@ -705,6 +708,26 @@ def main():
                 "job_frac": cells * args.steps / dt2 * ALGO_BYTES_PER_CELL_UPDATE / 1e9 / (HBM_PEAK_GBS * ranks_used),
                 "kernel_ms_per_iteration": ms2 / l2 if l2 else None,
                 "frac": ALGO_BYTES_PER_CELL_UPDATE * own_cells / (ms2 / l2 * 1e-3) / 1e9 / HBM_PEAK_GBS if l2 and ms2 > 0 else None}
+        # Which physical GPUs ran this (an N-rank line must prove it ran on N distinct GPUs, and a rehearsal must say so).
+        # Per rank: the HIP ordinal its process sees and the PCI bus id of that GPU, as the library reports them for the rank's
+        # context (wdpm_device_info).  `rehearsal` whenever the ranks share GPUs, or the RCCL that answered is not the ROCm one
+        # (tests/mock_rccl via WDPM_RCCL_LIB: its path is in `rccl`), or the halos do not travel GPU to GPU at all.
+        devices = [{"rank": i, "hip_ordinal": r["device"][0], "pci_bus_id": r["device"][1], "pid": r.get("pid")} for i, r in enumerate(per_rank)]
+        distinct = len({d["pci_bus_id"] for d in devices})
+        out["config"]["devices"] = devices
+        out["config"]["distinct_gpus"] = distinct
+        rccl_from = out["config"]["rccl"] or ""
+        standin = ranks_used > 1 and halo == "rccl" and "/opt/rocm" not in rccl_from and "librccl" not in os.path.basename(rccl_from.rstrip(")").split("(")[-1])
+        why = []
+        if distinct < ranks_used:
+            why.append(f"{ranks_used} ranks on {distinct} physical GPU{'s' if distinct != 1 else ''}")
+        if standin:
+            why.append(f"the RCCL entry points were bound from a stand-in ({rccl_from})")
+        if ranks_used > 1 and not str(halo).startswith(("rccl", "peer")):
+            why.append(f"halos are staged through the host ({halo})")
+        if why:
+            out["rehearsal"] = True
+            out["rehearsal_reason"] = "; ".join(why) + ": not a multi-GPU measurement"
         # chunk heights by XCD as rank 0 ended up with them: rebalances so far, the eight weights (which XCDs of this
         # box are slow, and by how much) and the factor on a strip's last chunk; all 1 / 0.95 where the balance did not engage
         out["config"]["xcd_balance"] = {"updates": per_rank[0]["balance"][0], "weights": [round(v, 4) for v in per_rank[0]["balance"][1]]}

@@ -186,6 +186,12 @@ int wdpm_balance_info(wdpm_ctx *ctx, int32_t *updates, double *weights9);
 /* what this library was built from: "kernels=<first 16 hex digits of the sha256 of the kernel sources> arch=... sched=..." - bench.py
  * quotes counter evidence collected on another run (profiles/traffic.json) only for a library that says the same */
 const char *wdpm_build_info(void);
+/* which physical GPU a context lives on: the HIP ordinal as this process sees it (HIP_VISIBLE_DEVICES renumbers) and the PCI bus id
+ * ("0000:c1:00.0", hipDeviceGetPCIBusId: one per GPU of a node whatever the ordinal; `len` >= 16 bytes).  bench.py gathers one per
+ * rank, so that an N-rank line shows N distinct GPUs - or says that it is a rehearsal on fewer.  Takes the place of
+ * the reference's device report (create_device() prints CL_DEVICE_NAME of the ONE device it picks, WDPMCL.c:80-121).
+ * The CPU restatement: ordinal -1, "host". */
+int wdpm_device_info(wdpm_ctx *ctx, int32_t *ordinal, char *pci_bus_id, int32_t len);
 
 /* copy `nrows` rows of the CURRENT water raster from slab-local row `src_row` of `src` to row
  * `dst_row` of `dst` (same raster width).  Device to device on the HIP back-end (peer copy over

@@ -155,6 +155,40 @@ def test_16_bit_offsets_are_refused_where_the_relief_is_too_steep(hip, oracle):
             assert n_bit_diff(g.download_water(), o.download_water()) == 0, span
 
 
+def test_a_rough_dem_uploaded_over_a_smooth_one_inherits_no_16_bit_offsets(hip, oracle):
+    """the 16-bit level is decided afresh by every upload.  A smooth DEM (offsets accepted), then - into the same context - a
+    DEM that passes the 32-bit check only: asking for the offsets must be refused, and the options must switch offsets, group bases
+    and their pitch together (DEM32 off and on again brings the offsets back only where they are valid)"""
+    if os.environ.get("WDPM_DEM16", "1") == "0":
+        pytest.skip("the forced-variant suite without offsets")
+    R, C, miss = 40, 300, -99999.0
+    kw = dict(module="add", nrows=R, ncols=C, missingvalue=miss)
+    smooth = np.full((R, C), 500.0003)
+    rough = smooth.copy()
+    rough[7, 100] = np.round(500.0003 + 200001 * 1e-4, 4)
+    rough[3, 50] = miss
+    avail = 1 if os.environ.get("WDPM_DEM32") == "2" else 2
+    with hip.context(kernel=wdpm_amd.KERNEL_FUSED, chunk_rows=12, **kw) as g:
+        g.upload(*pad(smooth, np.full((R, C), 0.05), miss))
+        assert g.get_option(wdpm_amd.capi.OPT_DEM16) == avail
+        g.set_option(wdpm_amd.OPT_DEM32, 0)
+        assert g.get_option(wdpm_amd.capi.OPT_DEM16) == 0
+        g.set_option(wdpm_amd.OPT_DEM32, 2)
+        assert g.get_option(wdpm_amd.capi.OPT_DEM16) == 1          # back, with their bases
+        g.iterate(3)
+        bd, bw = pad(rough, np.where(rough > miss, 0.05, 0.0), miss)
+        g.upload(bd, bw)
+        assert g.get_option(wdpm_amd.OPT_DEM32) == 1 and g.get_option(wdpm_amd.capi.OPT_DEM16) == 0
+        g.set_option(wdpm_amd.OPT_DEM32, 2)
+        g.set_option(wdpm_amd.capi.OPT_DEM16, 1)                    # must be refused: the offsets in memory are the smooth DEM's
+        assert g.get_option(wdpm_amd.capi.OPT_DEM16) == 0
+        g.iterate(6)
+        with oracle.context(**kw) as o:
+            o.upload(bd, bw)
+            o.iterate(6)
+            assert n_bit_diff(g.download_water(), o.download_water()) == 0
+
+
 def test_dem_codes_are_refused_for_non_decimal_elevations(hip, oracle):
     _compare_with_oracle(hip, oracle, "add", 60, 400, seed=77, iters=(5,), kernel=wdpm_amd.KERNEL_FUSED, dem32=1,
                          dem_digits=None)

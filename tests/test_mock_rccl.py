@@ -164,6 +164,12 @@ def test_bench_ranks_over_mock_rccl_processes(proc_env, one_rank_line):
     c = d["config"]
     assert d["n_gpus"] == 2 and c["halo"] == "rccl" and c["rccl_ranks"] == 2 and c["dist_backend"] == "gloo", c
     assert "degraded" not in d and "2.99.99" in c["rccl"] and c["exchange_every"] == 8
+    # ... and cannot be mistaken for a two-GPU measurement: the line names the GPU behind every rank and the library
+    # the RCCL entry points came from, and calls itself a rehearsal for both reasons
+    assert d["rehearsal"] is True and c["distinct_gpus"] == 1 and len(c["devices"]) == 2, d
+    assert c["devices"][0]["pci_bus_id"] == c["devices"][1]["pci_bus_id"] and c["devices"][0]["pid"] != c["devices"][1]["pid"]
+    assert "libmock_rccl" in c["rccl"] and "stand-in" in d["rehearsal_reason"] and "2 ranks on 1 physical GPU" in d["rehearsal_reason"]
+    assert "rehearsal" not in one_rank_line and one_rank_line["config"]["distinct_gpus"] == 1
     assert c["max_diff_m"] == one_rank_line["config"]["max_diff_m"]
     assert "sends over" in err                              # the stand-in says which wire ran (IPC-mapped memory or a file)
     wire = sorted({ln.split("sends over ")[1] for ln in err.splitlines() if "sends over " in ln})
@@ -180,6 +186,27 @@ def test_bench_four_ranks_over_mock_rccl_processes(proc_env):
     d1, _ = bench_line(dict(os.environ), "--size", "4096", "--steps", "20", "--warmup", "5")
     assert d4["n_gpus"] == 4 and d4["config"]["halo"] == "rccl" and d4["config"]["rccl_ranks"] == 4 and "degraded" not in d4
     assert d4["config"]["max_diff_m"] == d1["config"]["max_diff_m"]
+    assert d4["rehearsal"] is True and d4["config"]["distinct_gpus"] == 1
+
+
+def test_the_drivers_scale_command_at_full_size_over_mock_rccl_processes(proc_env):
+    """the driver's SCALE command - `bench.py --gpus N --steps 20 --warmup 5` at 16384^2, rank processes under
+    torch.distributed.run, the DEM shared through /dev/shm, gloo rendezvous, N-way ncclCommInitRank, the launcher's first time
+    limit - with FOUR rank processes: this pool's process guard kills a call with more than six processes on the card, this
+    test runner is one of them, and a margin of one is kept (eight rank processes of the row-block driver run on the CPU in
+    tests/test_rowblock.py::test_eight_rank_processes_over_gloo).  Same max diff as the one-GPU line of the metric's own
+    configuration, inside the launcher's first limit, and marked as the rehearsal it is."""
+    t = time.monotonic()
+    d, err = bench_line(proc_env, "--gpus", "4", "--steps", "20", "--warmup", "5", timeout=900)
+    secs = time.monotonic() - t
+    c = d["config"]
+    assert d["n_gpus"] == 4 and c["halo"] == "rccl" and c["rccl_ranks"] == 4 and "degraded" not in d, d
+    assert c["max_diff_m"] == 0.07270028139273618                     # = one GPU's after 25 iterations (tests/test_multi_gpu.py)
+    assert d["rehearsal"] is True and c["distinct_gpus"] == 1 and len({v["pid"] for v in c["devices"]}) == 4
+    assert len(d["per_rank"]["kernel_ms_per_iteration"]) == 4 and min(d["per_rank"]["refreshes"]) >= 2
+    assert "starting them once more" not in err and secs < 200.0, (secs, err[-2000:])     # self_launch's first limit for this command
+    with open(os.path.join(ROOT, "gpurun_out", "bench_gpus4_16384_rehearsal_one_gpu.json"), "w") as f:
+        json.dump(dict(d, wall_seconds_of_the_whole_command=round(secs, 1)), f)
 
 
 def test_bench_goes_on_with_host_halos_when_communicator_setup_hangs(proc_env, one_rank_line):

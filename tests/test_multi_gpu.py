@@ -218,6 +218,36 @@ def test_config_5_on_one_slab_per_gpu_equals_the_reference(hip, golden, monkeypa
     assert wdpm_amd.HALO_NAMES[halo] == "rccl"
 
 
+# ------------------------------------------------------------------------------------------- (b') the shipped binary on every GPU
+@pytest.mark.gpu
+@multi
+def test_the_shipped_wdpmcl_on_every_gpu_of_the_box(hip, tmp_path):
+    """`WDPM_GPUS=<all> WDPMCL add ...` - the path a user takes: one host thread per GPU, ncclCommInitAll from those
+    threads, halos by RCCL (replaces the reference's pick of ONE OpenCL device, WDPMCL.c:80-121,598-638) - on a synthetic
+    2048^2 DEM, two blocks of 1000 iterations: the report (minus wall clock) and the output raster are byte-identical to the
+    same command on one GPU."""
+    import hashlib
+    from test_cli import HIP_CLI, file_sha, strip_timing
+    n = 2048
+    dem = hip.synth_dem(n, n)
+    with open(tmp_path / "dem.asc", "w") as f:
+        f.write(f"ncols {n}\nnrows {n}\nxllcorner 0\nyllcorner 0\ncellsize 10\nNODATA_value -99999\n")
+        np.savetxt(f, dem, fmt="%.4f")
+    devs = phys(spread_over_devices(NDEV))
+    runs = {}
+    for tag, extra in (("one", {}), ("all", {"WDPM_DEVICES": ",".join(map(str, devs))} if FAKE_NDEV else {"WDPM_GPUS": str(len(devs))})):
+        env = {k: v for k, v in os.environ.items() if k not in ("WDPM_GPUS", "WDPM_DEVICES")}
+        p = subprocess.run([HIP_CLI, "add", "dem.asc", "NULL", f"{tag}.asc", "NULL", "100", "1.0", "1.0", "1", "1", "0.005", "2000"],
+                           cwd=tmp_path, capture_output=True, text=True, timeout=900, env=dict(env, **extra))
+        assert p.returncode == 0, p.stderr[-3000:]
+        runs[tag] = (hashlib.sha256(strip_timing(p.stdout).encode()).hexdigest(), file_sha(os.path.join(tmp_path, f"{tag}.asc")), p.stderr)
+    assert runs["all"][0] == runs["one"][0] and runs["all"][1] == runs["one"][1]
+    assert "halos by RCCL send/recv" in runs["all"][2] and f"{len(devs)} row blocks" in runs["all"][2], runs["all"][2][-1500:]
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", f"wdpmcl_gpus{len(devs)}.txt"), "w") as f:
+        f.write(runs["all"][2])
+
+
 # ------------------------------------------------------------------------------------------- (c) the bench line of an N-GPU run
 def _bench(*args, timeout=900):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args, "--no-cpu-baseline"], capture_output=True, text=True,
@@ -244,8 +274,16 @@ def test_bench_on_every_gpu_of_the_box():
     pr = d["per_rank"]
     assert len(pr["kernel_ms_per_iteration"]) == n and all(v > 0 for v in pr["kernel_ms_per_iteration"])
     assert len(pr["refresh_us"]) == n and len(pr["refreshes"]) == n and min(pr["refreshes"]) >= 2
-    if not FAKE_NDEV:
+    # the line certifies itself: one PCI bus id per rank, as the library reports them for the ranks' contexts
+    devs = c["devices"]
+    assert [v["rank"] for v in devs] == list(range(n)) and len({v["pid"] for v in devs}) == n
+    if FAKE_NDEV:
+        assert d["rehearsal"] is True and c["distinct_gpus"] == 1 and "1 physical GPU" in d["rehearsal_reason"], d
+    else:
+        assert c["distinct_gpus"] == n == len({v["pci_bus_id"] for v in devs}) and "rehearsal" not in d, (c["devices"], d.get("rehearsal_reason"))
+        assert "/librccl" in c["rccl"]               # the ROCm library answered, and says from where
         assert d["value"] > one["value"]             # more GPUs, more cell-updates per second: the least a scaling curve owes
+    assert "rehearsal" not in one and one["config"]["distinct_gpus"] == 1
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", f"bench_gpus{n}.json"), "w") as f:
         json.dump(d, f)

@@ -107,6 +107,26 @@ def test_multirank_equals_single_slab(oracle, world, k):
         assert list(g["mds"]) == mds
 
 
+@pytest.mark.parametrize("module", ["add", "drain"])
+def test_eight_rank_processes_over_gloo(oracle, module):
+    """N = 8 as rank PROCESSES (so far eight slabs had only run as threads of one process, and as rank processes two to
+    four): the driver's partition into eight row blocks, its chain of refreshes at the default interval k = 8 with the deep
+    halos that go with it (23 rows above, 46 below), the eight-way all-gather of the block scalars and, for drain, the
+    rank-chained volume sum - one process per rank over gloo, here on the CPU where eight processes are allowed (the GPU
+    pool's process guard stops at six on a card; four rank processes run there at 16384^2, tests/test_mock_rccl.py)."""
+    case = dict(seed=23, R=960, C=45, module=module, k=8, thres=0.005 / 1000, blocks=[19, 9])
+    want, mds = single(oracle, case)
+    stats = case.pop("_stats")
+    got = run_ranks(8, case)
+    assert [int(g["lo"]) for g in got] == sorted(int(g["lo"]) for g in got) and int(got[-1]["hi"]) == case["R"] + 1
+    for g in got:
+        lo, hi = int(g["lo"]), int(g["hi"])
+        assert bits_equal(g["own"], want[lo:hi + 1]), f"rows {lo}..{hi}: {n_bit_diff(g['own'], want[lo:hi + 1])} cells differ"
+        assert list(g["mds"]) == mds
+        if module == "drain":
+            assert g["stats"].tolist() == stats
+
+
 @pytest.mark.parametrize("world,k,R", [(2, 2, 150), (3, 1, 210)])
 def test_multirank_drain_equals_single_slab(oracle, world, k, R):
     """drain module across ranks: water, max diff, totaldrain, |d totaldrain| and the chained

@@ -102,6 +102,7 @@ SYMBOLS = {
     "wdpm_timing_get_exchange": (C.c_int, [_vp, C.POINTER(C.c_int64), _dp]),
     "wdpm_build_info": (C.c_char_p, []),
     "wdpm_balance_info": (C.c_int, [_vp, C.POINTER(C.c_int32), _dp]),
+    "wdpm_device_info": (C.c_int, [_vp, C.POINTER(C.c_int32), C.c_char_p, C.c_int32]),
     "wdpm_copy_rows": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, C.c_int32]),
     "wdpm_set_last_error": (None, [C.c_char_p]),
     "wdpm_enable_peer_access": (C.c_int, [_vp, _vp]),
@@ -406,6 +407,12 @@ class Context:
         n, w = C.c_int32(), (C.c_double * 9)()
         self.lib.check(self.lib.dll.wdpm_balance_info(self._h, C.byref(n), w))
         return n.value, [float(v) for v in w]
+
+    def device_info(self):
+        """(HIP ordinal as this process sees it, PCI bus id of the GPU the context lives on) - (-1, "host") on the CPU restatement"""
+        o, b = C.c_int32(), C.create_string_buffer(32)
+        self.lib.check(self.lib.dll.wdpm_device_info(self._h, C.byref(o), b, 32))
+        return o.value, b.value.decode()
 
     def timing_exchange(self):
         """(halo refreshes into this context, ms on its stream from queueing a transfer to its rows' arrival) since the last reset"""

@@ -278,7 +278,7 @@ int wdpm_create(wdpm_ctx **out, const wdpm_params *p) {
   x->flush_thres = -__builtin_inf();
   x->d_scal = nullptr; x->d_bits = nullptr; x->h_pin = nullptr; x->d_stat = nullptr;
   x->d_dem32 = nullptr; x->code = DemCode{nullptr, 0.0, 1.0, 1.0, 0, nullptr, nullptr, 0}; x->dem32_encodable = false; x->dem_bounded = false;
-  x->d_dem16 = nullptr; x->d_gbase = nullptr; x->dem16_encodable = false;
+  x->d_dem16 = nullptr; x->d_gbase = nullptr; x->dem16_encodable = false; x->dem16_wanted = true;
   x->d_sum_approx = nullptr; x->d_sum_i = nullptr; x->d_sum_k = nullptr; x->d_sum_flag = nullptr;
   x->own_stream = true;
   x->side = nullptr; x->ev_fork = nullptr; x->ev_join = nullptr; x->pending_join = false; x->ev_copy[0] = x->ev_copy[1] = nullptr;
@@ -423,9 +423,10 @@ static bool plain_water(const wdpm_ctx *x) {
  * (e = 0..6, the smallest that works; real DEMs are decimal text).  The device checks every cell
  * with the decoder the iteration kernel uses; any miss leaves the fp64 DEM in charge. */
 static int encode_dem(wdpm_ctx *x) {
-  x->dem32_encodable = false; x->dem_bounded = false;
-  x->dem_bounded = false;
-  x->code.q = nullptr;
+  /* every level starts from "not encodable": a DEM uploaded over an earlier one inherits nothing (a smooth DEM, then a
+   * rough one that passes only the 32-bit check, left dem16_encodable set and d_dem16 holding truncated offsets) */
+  x->dem32_encodable = false; x->dem16_encodable = false; x->dem_bounded = false; x->dem16_wanted = true;
+  x->code = DemCode{nullptr, 0.0, 1.0, 1.0, 0, nullptr, nullptr, 0};
   HIP_TRY(wdpm_launch_dem_min(x->d_dem, x->cells, x->d_bits, x->stream));
   HIP_TRY(hipMemcpyAsync(x->h_pin, x->d_bits, 2 * sizeof(double), hipMemcpyDeviceToHost, x->stream));
   if (wdpm_stream_sync(x, x->stream)) return 1;
@@ -710,12 +711,19 @@ int wdpm_set_option(wdpm_ctx *x, int32_t key, int64_t value) {
     if (value & WDPM_WATER_NEGZERO) x->signed_zero_safe = true;
     if (value & WDPM_WATER_NEGATIVE) x->w_negative = true;
     if (value & WDPM_WATER_ODD) x->w_odd = true;
-  } else if (key == WDPM_OPT_DEM32) {
-    /* switching it on is honoured only for a DEM that passed the device's bit-for-bit check */
-    x->code.q = (value != 0 && x->dem32_encodable) ? x->d_dem32 : nullptr;
-    x->code.force = value == 2;   /* 2: also on launches too small for the codes to pay (tests) */
-  } else if (key == WDPM_OPT_DEM16) {
-    x->code.h = (value != 0 && x->dem16_encodable) ? x->d_dem16 : nullptr;
+  } else if (key == WDPM_OPT_DEM32 || key == WDPM_OPT_DEM16) {
+    /* switching the codes on is honoured only for a DEM that passed the device's bit-for-bit check; the 16-bit offsets are
+     * offsets of the 32-bit codes, so they follow them, and offsets, group bases and their pitch go on and off together */
+    if (key == WDPM_OPT_DEM32) {
+      x->code.q = (value != 0 && x->dem32_encodable) ? x->d_dem32 : nullptr;
+      x->code.force = value == 2;   /* 2: also on launches too small for the codes to pay (tests) */
+    } else {
+      x->dem16_wanted = value != 0;
+    }
+    const bool on16 = x->dem16_wanted && x->dem16_encodable && x->code.q != nullptr;
+    x->code.h = on16 ? x->d_dem16 : nullptr;
+    x->code.gb = on16 ? x->d_gbase : nullptr;
+    x->code.ngroups = on16 ? (x->g.ncp + kDemGroup - 1) / kDemGroup : 0;
   } else if (key == WDPM_OPT_TILES) {
     x->tiles_mode = value != 0;
     x->zero_valid[0] = x->zero_valid[1] = x->zero_valid[2] = false;
@@ -1151,6 +1159,15 @@ int wdpm_timing_reset(wdpm_ctx *x) {
   x->xch_count = 0;
   x->xch_ms = 0.0;
   x->timing = true;
+  return 0;
+}
+
+int wdpm_device_info(wdpm_ctx *x, int32_t *ordinal, char *pci_bus_id, int32_t len) {
+  if (ordinal) *ordinal = x->p.device;
+  if (pci_bus_id) {
+    if (len < 16) return fail("wdpm_device_info: the PCI bus id needs 16 bytes, got %d", (int)len);
+    HIP_TRY(hipDeviceGetPCIBusId(pci_bus_id, len, x->p.device));
+  }
   return 0;
 }
 

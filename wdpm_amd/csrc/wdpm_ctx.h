@@ -69,6 +69,7 @@ struct wdpm_ctx {
   unsigned short *d_dem16;      /* the codes once more as 16-bit offsets from d_gbase (DemCode::h, ::gb); code.h is set while they are in use */
   int *d_gbase;
   bool dem16_encodable;
+  bool dem16_wanted;          /* WDPM_OPT_DEM16 as last set (default on); what runs is decided with dem16_encodable and code.q */
   XcdBalance bal;               /* chunk heights by what each XCD delivers (wdpm_kernels.h); bal.mode == 0: off */
   bool dem_bounded;             /* every valid elevation of the uploaded DEM is below 2^30 m in magnitude (scan_dem): the clamped
                                    neighbour step may run where the depths allow it (wdpm_kernels.h: WDPM_LAUNCH_CLAMP_OK) */

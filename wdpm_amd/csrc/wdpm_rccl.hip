@@ -371,10 +371,16 @@ int wdpm_comm_allgather(wdpm_ctx *x, const double *mine, int32_t n, double *all)
 }
 
 const char *wdpm_comm_version(void) {
-  static char v[64] = "";
+  /* version and the file the entry points were bound from (dladdr): a line that says "RCCL" also says WHICH library answered -
+   * /opt/rocm/lib/librccl.so.1 or a stand-in named by WDPM_RCCL_LIB (tests/mock_rccl; VERDICT r4: a rehearsal must be unmistakable) */
+  static char v[384] = "";
   if (need_rccl()) return "unavailable";
   int code = 0;
-  if (g_api.GetVersion(&code) == ncclSuccess) snprintf(v, sizeof v, "RCCL %d.%d.%d", code / 10000, (code / 100) % 100, code % 100);
+  if (g_api.GetVersion(&code) == ncclSuccess) {
+    Dl_info di;
+    const char *from = dladdr((void *)g_api.GetVersion, &di) && di.dli_fname ? di.dli_fname : "?";
+    snprintf(v, sizeof v, "RCCL %d.%d.%d (%s)", code / 10000, (code / 100) % 100, code % 100, from);
+  }
   return v;
 }
 

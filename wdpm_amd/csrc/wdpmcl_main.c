@@ -746,6 +746,18 @@ int main(int argc, char **argv) {
     fprintf(stderr, "WDPMCL: redistribution loop, set-up and statistics on back-end %s, %d device%s (first: %d)%s\n",
             wdpm_backend_name(), ndev, ndev == 1 ? "" : "s, row-block decomposition, one host thread per device", devices[0],
             ndev > 1 && hk >= 0 && hk < 4 ? halo_name[hk] : "");
+    /* ... and WHICH GPUs: one line per row block with the PCI bus id of the GPU it lives on (wdpm_device_info) - what the
+     * reference's create_device() says about the one OpenCL device it picks (WDPMCL.c:80-121) */
+    const int nblk = wdpm_group_size(ctx);
+    fprintf(stderr, "WDPMCL: %d row block%s", nblk, nblk == 1 ? "" : "s");
+    for (int i = 0; i < nblk; i++) {
+      int32_t ord = -1;
+      char bus[32] = "?";
+      wdpm_rank *rk = wdpm_group_rank(ctx, i);
+      if (rk && wdpm_device_info(wdpm_rank_ctx(rk), &ord, bus, (int32_t)sizeof bus) == 0)
+        fprintf(stderr, "%s block %d on device %d [%s]", i ? "," : ":", i, (int)ord, bus);
+    }
+    fprintf(stderr, "\n");
     if (getenv("WDPM_REPORT_BACKEND") && atoi(getenv("WDPM_REPORT_BACKEND")) != 0)   /* opt-in: the report is no longer the reference's */
       printf("%41s %s, %d device%s%s\n", "Computation back-end:", wdpm_backend_name(), ndev, ndev == 1 ? "" : "s (row blocks)",
              ndev > 1 && hk >= 0 && hk < 4 ? halo_name[hk] : "");
