@@ -216,12 +216,14 @@ def cpu_baseline(n=16384, full=False, quick=False):
     """The reference's own serial code if its prebuilt library is present (kind "reference"), else the
     CPU oracle (bit-equal port of it, kind "port"), timed on ONE host core (the reference's serial path is
     single-threaded) on bounded samples of the same workload.  The headline `value` is on the metric's own
-    configuration: the synthetic 16384^2 raster, 2 iterations of the serial loop (WDPMCL.c:1094-1106; about 13 s at
-    4.2e7 cell-updates/s - SURVEY.md §8d names 10 iterations, which `--cpu-baseline-full` runs: about a minute);
+    configuration: the synthetic 16384^2 raster, 5 iterations of the serial loop (WDPMCL.c:1094-1106; about 30 s at
+    4e7 cell-updates/s, the top of the bench contract's 10 - 30 s - SURVEY.md §8d names 10 iterations, which
+    `--cpu-baseline-full` runs: about a minute);
     beside it §8d's 1024^2 x 1000 iterations (cache-resident; later iterations of a settling raster take the slower
     branches) and 4096^2 x 24.  A reported baseline, never the product path."""
-    # the headline sample: the bench's own raster size, as many iterations as take about 13 s (never fewer than two)
-    head_iters = 10 if full and n >= 16384 else max(2, min(1000, int(round(5.5e8 / (float(n) * n)))))
+    # the headline sample: the bench's own raster size, as many iterations as take about 30 s (never fewer than two): FIVE at 16384^2
+    # (round 4 timed two; SURVEY 8d names ten, which `--cpu-baseline-full` runs in about a minute)
+    head_iters = 10 if full and n >= 16384 else max(2, min(1000, int(round(1.35e9 / (float(n) * n)))))
     samples = [(n, head_iters), (4096, 24), (1024, 1000)]
     if quick:        # tests of the line's shape only (--cpu-baseline-quick): seconds instead of a minute, not a baseline anybody should quote
         samples = [(n, 3), (4096, 1), (1024, 10)]
@@ -236,6 +238,9 @@ def cpu_baseline(n=16384, full=False, quick=False):
             **({"quick": "shape test only: a few iterations per sample"} if quick else {}),
             "sample": f"{what}, synthetic {head['size']}x{head['size']} all-wet add 100 mm (the metric's own raster), "
                       f"{head['iterations']} iterations after one untimed, {head['seconds']:.1f} s, one thread (the reference's serial path has no other)",
+            "spread_note": "the rate falls with the raster's size, not with the number of iterations timed: at 16384^2 the serial loop streams "
+                           "4.3 GB per iteration from DRAM through one core (rows of 131 KB behind row pointers), at 4096^2 and 1024^2 most "
+                           "of it stays in the host's caches; the 1000-iteration block of a settling raster is no slower than its first iterations",
             "samples": res}
 
 

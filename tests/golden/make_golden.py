@@ -344,7 +344,7 @@ def make_full_size(ref):
 # iterations, config 5 = drain at 8192^2 from "that raster's add-100-mm state after 1000 iterations".  Each case is
 # a process of its own (`settled CASE`), writes a part file next to this script's output and `merge` folds the
 # parts into full_size.npz.  Reference lines followed: WDPMCL.c:1055-1125 (block), :1239-1254 (max diff).
-SETTLED_CASES = ("cfg3", "cfg4", "cfg5", "cfg4long")
+SETTLED_CASES = ("cfg3", "cfg4", "cfg5", "cfg4long", "cfg3x")
 
 
 def _max_diff(w, w0, bd, missing):
@@ -441,6 +441,29 @@ def make_settled(ref, case):
                    time.perf_counter() - t, 2048, add_iters=1000, drain_iters=upto, drainrow=dr, draincol=dc, td0=td0,
                    flushed_before_drain=flushed, volume_sum=_seq_sum(w2, bd, missing))
             del w2
+    elif case == "cfg3x":
+        # The regimes the all-wet configurations above never reach at full size (after 1000 iterations of add 100 mm every cell is
+        # still wet and the deepest pond is 1.1 m): DEEP water (the clamped neighbour step's guard, > 3 m in a wave's window) and a
+        # mostly DRY raster (dry tiles, water arriving in tiles that were skipped).  4096^2, 12 m of water (flows of 1.5 m: a clamped step would be WRONG here) on one 256 x 256 block in
+        # eight (a fixed pattern: block (bi, bj) is wet when (3 bi + 5 bj) % 8 == 0), two blocks of 200 iterations.
+        n = 4096
+        bd, _ = start(n)
+        bi, bj = np.mgrid[0:n, 0:n] // 256
+        bw = np.zeros_like(bd)
+        bw[1:-1, 1:-1] = np.where((3 * bi + 5 * bj) % 8 == 0, 12.0, 0.0)
+        del bi, bj
+        ref.ref_setup(n, n, missing, bd.ctypes.data, bw.ctypes.data, 0.0, 0, 0)
+        ref.ref_iterate(ADD, 200)
+        w1 = ref_water(ref, bd.shape)
+        record("cfg3x_ponds_4096_i200", n, ADD, w1, bw, bd, 0.0, time.perf_counter() - t, 512, add_iters=200, blocks=[200],
+               water_in="12.0 m where (3 * (i // 256) + 5 * (j // 256)) % 8 == 0 (file coordinates), else 0")
+        flushed = int(np.count_nonzero((w1 < thres) & (w1 != 0)))
+        w1[w1 < thres] = 0
+        ref.ref_setup(n, n, missing, bd.ctypes.data, w1.ctypes.data, 0.0, 0, 0)
+        ref.ref_iterate(ADD, 200)
+        w2 = ref_water(ref, bd.shape)
+        record("cfg3x_ponds_4096_b2_i400", n, ADD, w2, w1, bd, 0.0, time.perf_counter() - t, 512, add_iters=400,
+               blocks=[200, 200], flushed_before_block2=flushed)
     else:
         sys.exit(f"unknown case {case}; one of {SETTLED_CASES}")
 

@@ -61,11 +61,11 @@ def test_cpu_baseline_samples_of_the_default_command():
     spec.loader.exec_module(mod)
     seen = []
     mod.reference_baseline = lambda samples: (seen.append(list(samples)) or [{"size": n, "iterations": k, "seconds": 1.0, "value": 1.0} for n, k in samples])
-    assert mod.cpu_baseline(16384)["samples"][0]["size"] == 16384 and seen[-1] == [(16384, 2), (4096, 24), (1024, 1000)]
+    assert mod.cpu_baseline(16384)["samples"][0]["size"] == 16384 and seen[-1] == [(16384, 5), (4096, 24), (1024, 1000)]
     mod.cpu_baseline(16384, full=True)
     assert seen[-1][0] == (16384, 10)
     mod.cpu_baseline(1024)
-    assert seen[-1][0] == (1024, 525)
+    assert seen[-1][0] == (1024, 1000)
 
 
 def test_counter_evidence_is_quoted_for_the_headline_configuration_and_build():
@@ -77,9 +77,11 @@ def test_counter_evidence_is_quoted_for_the_headline_configuration_and_build():
     spec = importlib.util.spec_from_file_location("bench_counters", os.path.join(ROOT, "bench.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
+    if not os.path.exists(wdpm_amd.capi.HIP_LIB_PATH):      # a checkout that has built the oracle only
+        pytest.skip("the HIP library is not built here: nothing to tie the counters to")
     lib = wdpm_amd.load_hip()
     build = lib.dll.wdpm_build_info().decode()
-    assert build.startswith("kernels=") and "arch=gfx950" in build
+    assert build.startswith("kernels=") and " arch=" in build and " sched=" in build
     with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
         t = json.load(f)
     c = mod.measured_counters(lib, 16384, 1, "auto", "dem16")

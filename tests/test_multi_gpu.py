@@ -237,10 +237,11 @@ def test_the_shipped_wdpmcl_on_every_gpu_of_the_box(hip, tmp_path):
     runs = {}
     for tag, extra in (("one", {}), ("all", {"WDPM_DEVICES": ",".join(map(str, devs))} if FAKE_NDEV else {"WDPM_GPUS": str(len(devs))})):
         env = {k: v for k, v in os.environ.items() if k not in ("WDPM_GPUS", "WDPM_DEVICES")}
-        p = subprocess.run([HIP_CLI, "add", "dem.asc", "NULL", f"{tag}.asc", "NULL", "100", "1.0", "1.0", "1", "1", "0.005", "2000"],
-                           cwd=tmp_path, capture_output=True, text=True, timeout=900, env=dict(env, **extra))
+        os.makedirs(tmp_path / tag)                        # (the report names its files: the same names in two directories)
+        p = subprocess.run([HIP_CLI, "add", "../dem.asc", "NULL", "out.asc", "NULL", "100", "1.0", "1.0", "1", "1", "0.005", "2000"],
+                           cwd=tmp_path / tag, capture_output=True, text=True, timeout=900, env=dict(env, **extra))
         assert p.returncode == 0, p.stderr[-3000:]
-        runs[tag] = (hashlib.sha256(strip_timing(p.stdout).encode()).hexdigest(), file_sha(os.path.join(tmp_path, f"{tag}.asc")), p.stderr)
+        runs[tag] = (hashlib.sha256(strip_timing(p.stdout).encode()).hexdigest(), file_sha(os.path.join(tmp_path, tag, "out.asc")), p.stderr)
     assert runs["all"][0] == runs["one"][0] and runs["all"][1] == runs["one"][1]
     assert "halos by RCCL send/recv" in runs["all"][2] and f"{len(devs)} row blocks" in runs["all"][2], runs["all"][2][-1500:]
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)

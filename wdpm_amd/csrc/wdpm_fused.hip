@@ -352,6 +352,29 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
   // A workgroup is eight waves where the launch puts two waves on every SIMD (one workgroup per CU: the two waves of a SIMD can
   // then see each other's progress in LDS - see `prio` in the marching loop), four where it leaves half of the slots empty.
   const int item = vb * (int)(blockDim.x >> 6) + wave;
+  // Which two waves of this workgroup share a SIMD (see `prio` in the marching loop): settled by the waves themselves.
+  // Rounds 3 - 4 took "SIMD id x 2 + the low bit of the wave slot" from HW_ID, which pairs two waves only while they sit in slots
+  // that differ in bit 0 - true on an empty chip, not when other kernels hold slots (RCCL's send / recv kernels during the overlapped
+  // iteration of an N-GPU run, the tail of the previous launch): slots 0 / 2 then share a word, each wave reads its own step
+  // number back and the mechanism switches itself off.  Now every wave takes a seat at its SIMD (an LDS counter per SIMD id);
+  // seats 0 and 1 of a SIMD are a pair, anything else (a SIMD with one or three of this workgroup's waves) runs without priorities.
+  __shared__ int progress_all[8];                        // a pair's two step numbers: words 2 * SIMD + seat
+  __shared__ int simd_seats[4];
+  int my_word = 0;
+  bool paired = false;
+  if (prio) {                                            // the same in every wave of the launch: all of them reach the barriers
+    if (threadIdx.x < 8) progress_all[threadIdx.x] = 0;
+    if (threadIdx.x < 4) simd_seats[threadIdx.x] = 0;
+    __syncthreads();
+    const int simd = (int)((__builtin_amdgcn_s_getreg((31 << 11) | 4) >> 4) & 3);      // HW_ID: SIMD [5:4]
+    int seat = 0;
+    if (lane == 0) seat = atomicAdd(&simd_seats[simd], 1);
+    seat = __builtin_amdgcn_readfirstlane(seat);
+    __syncthreads();
+    paired = seat < 2 && simd_seats[simd] == 2;
+    my_word = 2 * simd + (seat & 1);
+  }
+  const int use_prio = paired ? 1 : 0;
   if (item >= nitems) return;                       // wave-uniform
 #ifdef WDPM_WAVE_TIMES
   const unsigned long long wt0 = wall_clock64();
@@ -433,10 +456,7 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
     for (int k = 0; k < 3; k++) { scol[k] = lo + 64 * k + lane < hi ? lo + 64 * k + lane : hi; soff[k] = 8u * (unsigned)scol[k]; }
   }
   __shared__ double stage_all[8][3 * kStripIn];          // 4.5 KiB per wave, private to the wave
-  __shared__ int progress_all[8];                        // see `prio` in the marching loop
   double *const stage_lds = stage_all[wave];
-  const unsigned hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4);                   // HW_ID: wave slot [3:0], SIMD [5:4]
-  const int my_word = (int)(((hw_id >> 4) & 3) * 2 + (hw_id & 1));
   volatile int *const my_progress = progress_all + my_word;
   volatile int *const partner_progress = progress_all + (my_word ^ 1);
   bool cdr[5];
@@ -519,11 +539,18 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
       for (int i = 0; i < 3; i++) {
         int r = r0 + i;
         if (EDGE) r = r < g.rows ? r : g.rows - 1;
-        const double *bw = win + (size_t)r * pitch;     // wave-uniform
-        const double *bd = dem + (size_t)r * pitch;
-        const int *bq = code.q + (size_t)r * pitch;
-        const unsigned short *bh = code.h + (size_t)r * pitch;
-        const int *bg = code.gb + (size_t)r * code.ngroups;
+#ifdef WDPM_ABLATE_HBM   /* timing experiments only (tools/hbm_ablation.sh): what the kernel costs when its rows come from / go to the caches
+                            instead of HBM.  Bits: 1 = the water loads come from the raster's first 48 rows, 2 = the stores land there,
+                            4 = the DEM loads come from there.  Same instructions, same number of memory operations, wrong results. */
+        const int rw = (WDPM_ABLATE_HBM & 1) ? r % 48 : r, rdm = (WDPM_ABLATE_HBM & 4) ? r % 48 : r;
+#else
+        const int rw = r, rdm = r;
+#endif
+        const double *bw = win + (size_t)rw * pitch;     // wave-uniform
+        const double *bd = dem + (size_t)rdm * pitch;
+        const int *bq = code.q + (size_t)rdm * pitch;
+        const unsigned short *bh = code.h + (size_t)rdm * pitch;
+        const int *bg = code.gb + (size_t)rdm * code.ngroups;
         asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(P.NW[i][0]) : "v"(voff0), "s"(bw) : "memory");
         asm volatile("global_load_dwordx2 %0, %1, %2 offset:8" : "=v"(P.NW[i][1]) : "v"(voff0), "s"(bw) : "memory");
         asm volatile("global_load_dwordx2 %0, %1, %2 offset:16" : "=v"(P.NW[i][2]) : "v"(voff0), "s"(bw) : "memory");
@@ -584,7 +611,11 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
         const int r = rb + i;
         const bool row_ok = r >= or_lo && r <= or_hi;             // wave-uniform
         // rows outside the chunk's output range (first / last trips only) go to the dump area
+#ifdef WDPM_ABLATE_HBM
+        char *const orow = row_ok ? reinterpret_cast<char *>(wout + (size_t)((WDPM_ABLATE_HBM & 2) ? r % 48 : r) * pitch + c0) : dump;
+#else
         char *const orow = row_ok ? reinterpret_cast<char *>(wout + (size_t)r * pitch + c0) : dump;   // wave-uniform
+#endif
         // Stores as inline asm, saddr form: a wave-uniform row base in SGPRs + the lane's byte offset, no address arithmetic on
         // the vector unit.  Ordinary stores, not non-temporal ones (round 4).  Rounds 1 - 3 believed they were choosing between
         // the two by size: left to the compiler, the two arms of that branch (the same store with and without !nontemporal)
@@ -601,7 +632,7 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
     auto step = [&](const int n, Prefetched &P, auto nstages_tag) {
       constexpr int NSTAGES = decltype(nstages_tag)::value;
       int partner_at = 0;
-      if (prio) {                                        // wave-uniform
+      if (use_prio) {                                    // wave-uniform
         *my_progress = n;                                // every lane the same word
         partner_at = *partner_progress;                  // read back after the step's arithmetic
       }
@@ -701,7 +732,7 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
         }
       nzmask |= __ballot((any_lo | any_hi) != 0);
       __builtin_amdgcn_wave_barrier();
-      if (prio) {
+      if (use_prio) {
         const int p = __builtin_amdgcn_readfirstlane(partner_at);
         if (p > n) __builtin_amdgcn_s_setprio(3);        // the other wave of this SIMD is ahead: this one is served first
         else if (p < n) __builtin_amdgcn_s_setprio(0);
@@ -726,11 +757,11 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
     // fractions different for the two slots, from a two-wave model of the arbiter): 0.96 in flight at 16384^2 (+5.6 %), but nothing
     // or a loss on chunks of fewer than ~40 steps - 4096^2, every 8-GPU slab - and an instantiation of its own.
     // Round 4: the two waves TELL each other where they are.  With two waves per SIMD a workgroup is eight waves, one workgroup
-    // per CU, so the two waves of a SIMD share LDS: each step a wave writes its step number to its word (SIMD id x 2 + the low
-    // bit of its wave slot, from HW_ID) and reads the other's; whoever is behind gets priority 3, whoever is ahead 0, level 1
-    // when they are level (the older then leads by a step, and is overtaken).  Two LDS operations and a few scalar
-    // instructions per step, no assumption about chunk heights or about who started first; a partner that has finished, or
-    // never existed, reads as "ahead" or as garbage - either way only who issues first is decided here, never what is computed.
+    // per CU, so the two waves of a SIMD share LDS: each step a wave writes its step number to its word (SIMD id x 2 + the
+    // seat it took there at the start of the kernel) and reads the other's; whoever is behind gets priority 3, whoever is ahead 0,
+    // level 1 when they are level (the older then leads by a step, and is overtaken).  Two LDS operations and a few scalar
+    // instructions per step, no assumption about chunk heights or about who started first; a partner that has finished keeps its
+    // last step number and reads as "ahead" until it is passed - either way only who issues first is decided here, never what is computed.
     // `prio` = 0 (WDPM_PRIO=0, or a launch of four-wave workgroups): no priorities.
     Prefetched P;
     prefetch(P, A);
@@ -1372,7 +1403,8 @@ relay_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
  * per chunk, the last boundary at the launch's last triple.  One workgroup; the sums are cleared for the next measurement. */
 __global__ void __launch_bounds__(256)
 xcd_rebalance_kernel(float *__restrict__ weight, unsigned long long *__restrict__ acc, int *__restrict__ table, const int nstrips,
-                     const int nchunks, const int A0, const int out_last, const int ipx, const int update, const int from_uniform) {
+                     const int nchunks, const int A0, const int out_last, const int ipx, const int update, const int from_uniform,
+                     const int pair) {
   __shared__ float w[9];
   if (threadIdx.x == 0) {
     float mean[9], m = 0.f;
@@ -1415,9 +1447,16 @@ xcd_rebalance_kernel(float *__restrict__ weight, unsigned long long *__restrict_
     float cum = 0.f;
     int prev = 0;
     table[s] = A0;
+    // `pair` (round 5): heights come in whole row triples, so where a chunk is a few triples tall (an 8-GPU slab: 8.4) some chunks are
+    // a triple taller than others - and a launch of one resident round ends with its busiest SIMD, i.e. with the pair of waves that
+    // holds two tall chunks.  The two waves of a SIMD are waves w and w + 4 of an eight-wave workgroup, work items four apart: strips
+    // s and s + 4 of one chunk row.  Rounding the boundaries of those two strips half a triple apart puts the tall chunks of one
+    // beside the short chunks of the other (exactly so for equal weights: with a fractional height f <= 1/2 two tall chunks never
+    // meet, with f > 1/2 two short ones never do), and every SIMD gets the same number of steps to within one.
+    const float phase = pair ? (((s >> 2) & 1) ? 0.75f : 0.25f) : 0.5f;
     for (int c = 0; c < nchunks; c++) {
       cum += wgt(c, s);
-      int t = c == nchunks - 1 ? T : (int)((float)T * cum / total + 0.5f);
+      int t = c == nchunks - 1 ? T : (int)((float)T * cum / total + phase);
       const int lo = prev + 2, hi = T - 2 * (nchunks - 1 - c);
       t = t < lo ? lo : t;
       t = t > hi ? hi : t;
@@ -1716,9 +1755,9 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
   // chunk i stores rows [A0+H*i+2 (0 for A0+H*i = 0), A0+H*(i+1)+1]; the last must reach out_last
   int nchunks = (out_last - A0 - 1 + H - 1) / H;
   if (nchunks < 1) nchunks = 1;
-  const int nitems = nstrips * nchunks;
+  int nitems = nstrips * nchunks;
   const int wpb = two_per_simd ? 8 : 4;                            // waves per workgroup (see the kernel: `prio`)
-  const dim3 grid(((nitems + wpb - 1) / wpb + 7) / 8 * 8), block(64 * wpb);   // multiple of 8: see the XCD remap
+  dim3 grid(((nitems + wpb - 1) / wpb + 7) / 8 * 8), block(64 * wpb);   // multiple of 8: see the XCD remap
   TileFlags tf{nullptr, nullptr, 0, nullptr, nchunks};
   if (tiles && tiles->zout && fast && H >= 6 && A0 == 0 && out_last == g.rows - 1 &&
       (nstrips + 2) * (nchunks + 2) <= tiles->capacity) {
@@ -1744,15 +1783,31 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
   BalanceArgs ba{nullptr, nullptr};
   const bool bal_forced = bal && bal->mode == 2;          /* tests: the table on launches of any size, from skewed weights */
   if (bal && bal->mode && (two_per_simd || bal_forced) && A0 == 0 && out_last == g.rows - 1 && (chunk_rows < 3 || bal_forced) && nchunks >= 2) {
-    const int ipx = wpb * (int)(grid.x / 8);
     const bool can_table = !tf.zout && H >= (bal_forced ? 6 : 12) && (nchunks + 1) * nstrips <= bal->capacity;
+    // Round 5: with the table in charge a strip's chunks need not be equally tall, so a strip is cut into as many chunks as the
+    // resident round has slots for - equal heights in whole triples left slots empty (the 8-GPU drain slab, 1055 x 8190: 27-row
+    // chunks, 39 x 48 = 1872 waves on 2048 slots) - and the table pairs tall chunks with short ones on every SIMD (`pair` in
+    // xcd_rebalance_kernel).  WDPM_PAIR=0: round 4's geometry (A/B, tests).
+    static std::atomic<int> env_pair{-1};
+    if (env_pair < 0) { const char *t = getenv("WDPM_PAIR"); env_pair = t ? atoi(t) : 1; }
+    const int pair = (wpb == 8 && !bal_forced && env_pair.load(std::memory_order_relaxed) != 0) ? 1 : 0;
+    if (can_table && pair) {
+      const int T = (out_last - 1 - A0 + 2) / 3, nc = slots / nstrips;
+      if (nc > nchunks && T / nc >= 4 && (nc + 1) * nstrips <= bal->capacity) {
+        nchunks = nc;
+        nitems = nstrips * nchunks;
+        grid = dim3(((nitems + wpb - 1) / wpb + 7) / 8 * 8);
+        tf.nchunks = nchunks;
+      }
+    }
+    const int ipx = wpb * (int)(grid.x / 8);
     const bool steady = !flush && !fold_md;
     if (can_table) {
       const bool same = bal->nstrips == nstrips && bal->nchunks == nchunks && bal->A0 == A0 && bal->out_last == out_last && bal->ipx == ipx;
       const bool update = bal->measured >= 3 && (same || bal->measured_uniform);
       if (!same || update) {
         hipLaunchKernelGGL(xcd_rebalance_kernel, dim3(1), dim3(256), 0, s, bal->weight, bal->acc, bal->table, nstrips, nchunks, A0,
-                           out_last, ipx, update ? 1 : 0, bal->measured_uniform);
+                           out_last, ipx, update ? 1 : 0, bal->measured_uniform, pair);
         bal->measured_uniform = 0;
         bal->nstrips = nstrips; bal->nchunks = nchunks; bal->A0 = A0; bal->out_last = out_last; bal->ipx = ipx;
         bal->measured = 0;
