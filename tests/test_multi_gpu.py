@@ -218,6 +218,32 @@ def test_config_5_on_one_slab_per_gpu_equals_the_reference(hip, golden, monkeypa
     assert wdpm_amd.HALO_NAMES[halo] == "rccl"
 
 
+@pytest.mark.gpu
+@multi
+def test_the_settled_configurations_on_one_slab_per_gpu_equal_the_reference(hip, monkeypatch):
+    """round 5: the configurations as SURVEY 8d words them (tests/test_settled_golden.py) on one row block per GPU over the real
+    RCCL - config 3's two blocks of 1000 with the flush between them, config 4 after 100 iterations, config 5's drain block from the
+    settled add state, and the 12 m ponds on a mostly dry raster (dry tiles and water arriving through refreshed halos)"""
+    import test_settled_golden as sg
+    monkeypatch.setenv("WDPM_HALO", "rccl")
+    z, idx = sg.load_golden()
+    devices = phys(spread_over_devices(NDEV))
+    done = []
+    if "cfg3_add_4096_b2_i2000" in idx:
+        sg.job_two_blocks(hip, z, idx, "cfg3_add_4096_i1000", "cfg3_add_4096_b2_i2000", devices)
+        done.append("cfg3")
+    if "cfg4_add_16384_i100" in idx:
+        sg.job_one_block(hip, z, idx["cfg4_add_16384_i100"], devices)
+        done.append("cfg4")
+    if "cfg5_drain_8192_a1000_d1000" in idx:
+        assert wdpm_amd.HALO_NAMES[sg.job_config5(hip, z, idx, devices)] == "rccl"
+        done.append("cfg5")
+    if "cfg3x_ponds_4096_b2_i400" in idx:
+        sg.job_two_blocks(hip, z, idx, "cfg3x_ponds_4096_i200", "cfg3x_ponds_4096_b2_i400", devices, water=sg.ponds)
+        done.append("cfg3x")
+    assert done, "no settled entry in tests/golden/full_size.npz"
+
+
 # ------------------------------------------------------------------------------------------- (b') the shipped binary on every GPU
 @pytest.mark.gpu
 @multi

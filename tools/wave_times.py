@@ -21,7 +21,7 @@ kw = {}
 if module == "drain":
     k = int(np.argmin(np.where(bd > 0, bd, np.inf))); kw = dict(drainrow=k // (C + 2), draincol=k % (C + 2))
 with lib.context(module=module, nrows=R, ncols=C, missingvalue=-99999.0, kernel=wdpm_amd.KERNEL_FUSED, **kw) as c:
-    c.upload(bd, bw); c.run_block(20, 0.0); c.iterate(30); c.synchronize()
+    c.upload(bd, bw); c.run_block(20, 0.0); c.iterate(int(os.environ.get('WT_WARM', '30'))); c.synchronize()
     for rep in range(3):
         c.iterate(5); c.synchronize()
         buf = np.zeros((8192, 4), dtype=np.uint64)
@@ -47,6 +47,17 @@ with lib.context(module=module, nrows=R, ncols=C, missingvalue=-99999.0, kernel=
             m = xcc == x
             if m.any():
                 print("   XCD %d: %4d waves, median duration %.1f, last end %.1f us" % (x, m.sum(), np.median(dur[m]), e[m].max()))
+        # per SIMD (XCD, the hardware id above the SIMD bits, SIMD): how many waves it held, when its last one ended - a launch of one
+        # resident round ends with its busiest SIMD (round 5: tall chunks paired with short ones per SIMD)
+        hw = (t[:, 2] & np.uint64(0xffffffff)).astype(np.int64)
+        key = xcc.astype(np.int64) * (1 << 32) + (hw >> 8) * 4 + simd
+        uk, inv = np.unique(key, return_inverse=True)
+        cnt = np.bincount(inv); last_end = np.zeros(len(uk)); np.maximum.at(last_end, inv, e)
+        tot = np.bincount(inv, weights=dur)
+        print("   SIMDs holding waves: %d (1 wave: %d, 2: %d, more: %d); a SIMD's last end  p10 %.1f  p50 %.1f  p90 %.1f  max %.1f us; sum of its waves' durations p50 %.1f max %.1f" %
+              (len(uk), (cnt == 1).sum(), (cnt == 2).sum(), (cnt > 2).sum(), *np.percentile(last_end, [10, 50, 90, 100]), np.median(tot), tot.max()))
+        by_chunk = [round(float(np.median(dur[chunk == k])), 1) for k in range(chunk.max() + 1)]
+        print("   median duration by chunk row:", by_chunk[:12], "..." if len(by_chunk) > 24 else "", by_chunk[12:] if len(by_chunk) <= 24 else by_chunk[-12:])
         last = np.argsort(e)[-8:]
         print("   last to end (strip, chunk, xcd, start, end):", [(int(strip[i]), int(chunk[i]), int(xcc[i]), round(float(s[i]), 1), round(float(e[i]), 1)) for i in last])
         first = np.argsort(e)[:4]
