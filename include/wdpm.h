@@ -75,7 +75,10 @@ int  wdpm_abi_version(void);
 
 /* -- data movement --------------------------------------------------------------------------
  * upload: replaces the two blocking clEnqueueWriteBuffer calls (WDPMCL.c:1143-1153).
- * Arrays hold slab_rows x (ncols+2) doubles (the context's slab only). */
+ * Arrays hold slab_rows x (ncols+2) doubles (the context's slab only) and carry the reference's 1-cell border: the first and last
+ * column - and, where the slab holds them, the raster's first and last row - have bigdem <= missingvalue and no water, as the
+ * reference builds them (WDPMCL.c:796-807).  The serial loops never make a border cell a centre (rows 1..R, columns 1..C,
+ * :1079-1080,1097-1098) and reach it as a neighbour only to find it NODATA (:1944,:1976); both back-ends rest on exactly that. */
 int wdpm_upload(wdpm_ctx *ctx, const double *bigdem, const double *bigwater);
 int wdpm_upload_water(wdpm_ctx *ctx, const double *bigwater);
 /* download: replaces clEnqueueReadBuffer of bigwater (WDPMCL.c:1217-1221) */

@@ -16,7 +16,7 @@ def table(T, nchunks, nstrips, weights, ipx, pair):
     for s in range(nstrips):
         def wgt(c):
             x = min((c * nstrips + s) // ipx, 7)
-            return w[x] * (w[8] if c == nchunks - 1 else np.float32(1.0))
+            return w[x] * (w[8] if c == nchunks - 1 else w[9] if c == 0 else np.float32(1.0))
         total = np.float32(sum(wgt(c) for c in range(nchunks)))
         phase = (0.75 if (s >> 2) & 1 else 0.25) if pair else 0.5
         cum, prev = np.float32(0), 0
@@ -39,7 +39,7 @@ def launch_geometry(rows, ncp, slots=2048):
 def test_partner_strips_take_turns_at_the_tall_chunks(rows, ncp):
     nstrips, nchunks, T = launch_geometry(rows, ncp)
     ipx = 8 * ((nstrips * nchunks + 7) // 8 + 7) // 8 * 8 // 8
-    uniform = [1.0] * 8 + [1.0]
+    uniform = [1.0] * 10
     worst = {}
     for pair in (0, 1):
         t = table(T, nchunks, nstrips, uniform, ipx, pair)
@@ -66,7 +66,7 @@ def test_the_drain_slab_of_an_8_gpu_run_fills_its_slots():
     11 steps for everyone; the table cuts a strip into 42 chunks of 8 or 9 triples, and no SIMD holds two of the tall ones"""
     nstrips, nchunks, T = launch_geometry(1055, 8192)
     assert (nstrips, nchunks, T) == (48, 42, 351) and nstrips * nchunks == 2016
-    h = np.diff(table(T, nchunks, nstrips, [1.0] * 9, 8 * 32, 1), axis=0)
+    h = np.diff(table(T, nchunks, nstrips, [1.0] * 10, 8 * 32, 1), axis=0)
     assert set(np.unique(h)) == {8, 9}
     s = np.arange(nstrips)
     assert ((h + h[:, s ^ 4]) <= 17).all()
@@ -77,6 +77,6 @@ def test_skewed_weights_keep_the_table_a_tiling():
     for _ in range(50):
         nstrips, nchunks = int(rng.integers(1, 100)), int(rng.integers(2, 90))
         T = int(rng.integers(2 * nchunks, 40 * nchunks))
-        w = list(rng.uniform(0.7, 1.4, 8)) + [float(rng.uniform(0.75, 1.2))]
+        w = list(rng.uniform(0.7, 1.4, 8)) + [float(rng.uniform(0.75, 1.2)), float(rng.uniform(0.75, 1.2))]
         t = table(T, nchunks, nstrips, w, max(8, nstrips * nchunks // 8), int(rng.integers(0, 2)))
         assert (t[0] == 0).all() and (t[-1] == T).all() and (np.diff(t, axis=0) >= 2).all()

@@ -10,7 +10,9 @@ cases in a child process (the switches are read once per process), bit for bit a
   the marching kernel on every size          WDPM_RELAY=0 WDPM_TRI=0, DEM codes on every launch (WDPM_DEM32=2), chunk heights from
                                              deliberately skewed per-XCD weights (WDPM_BALANCE=2)
   the relay kernel on every size             WDPM_RELAY=2, four-wave and eight-wave workgroups, stage priorities forced
-  the triangle kernel on every size          WDPM_TRI=2 WDPM_RELAY=0, three and six rows per wave"""
+  the triangle kernel on every size          WDPM_TRI=2 WDPM_RELAY=0, three and six rows per wave
+  (round 5) the marching kernel on every size with every slot of the resident round filled - chunks down to two row triples - and the
+  row boundaries of partner strips rounded half a triple apart    WDPM_BALANCE=2 WDPM_PAIR=2"""
 import os
 import subprocess
 import sys
@@ -23,7 +25,7 @@ pytestmark = pytest.mark.gpu
 
 SUITE = ["tests/test_hip_parity.py::test_golden_stencil_vectors", "tests/test_hip_parity.py::test_random_rasters_match_oracle",
          "tests/test_hip_parity.py::test_dem_codes_on_and_off", "tests/test_hip_parity.py::test_dem_codes_as_16_bit_offsets_on_and_off",
-         "tests/test_hip_parity.py::test_adversarial_operands",
+         "tests/test_hip_parity.py::test_adversarial_operands", "tests/test_hip_parity.py::test_drain_on_codes_with_nodata_around_the_outlet",
          "tests/test_hip_parity.py::test_drain_outlet_at_every_window_position", "tests/test_hip_parity.py::test_block_loop_matches_oracle",
          "tests/test_hip_parity.py::test_every_height_around_chunk_boundaries", "tests/test_hip_parity.py::test_every_width_around_strip_boundaries",
          "tests/test_hip_parity.py::test_negative_and_nan_inputs_are_handled_like_the_reference", "tests/test_hip_parity.py::test_degenerate_shapes",
@@ -32,6 +34,8 @@ SUITE = ["tests/test_hip_parity.py::test_golden_stencil_vectors", "tests/test_hi
 VARIANTS = {
     "gated-unclamped-no-priorities-no-offsets": dict(WDPM_PLAIN="0", WDPM_CLAMP="0", WDPM_PRIO="0", WDPM_DEM16="0"),
     "marching-everywhere-codes-skewed-heights": dict(WDPM_RELAY="0", WDPM_TRI="0", WDPM_DEM32="2", WDPM_BALANCE="2"),
+    # round 5: the table with every slot of the resident round filled (chunks down to two row triples) and partner strips rounded half a triple apart
+    "marching-everywhere-skewed-heights-slots-filled-paired": dict(WDPM_RELAY="0", WDPM_TRI="0", WDPM_BALANCE="2", WDPM_PAIR="2"),
     "relay-everywhere-four-waves": dict(WDPM_RELAY="2", WDPM_RELAY_NW="4", WDPM_RELAY_PRIO="2"),
     "relay-everywhere-eight-waves-codes": dict(WDPM_RELAY="2", WDPM_RELAY_NW="8", WDPM_DEM32="2", WDPM_RELAY_PRIO="2"),
     "triangle-everywhere-six-rows": dict(WDPM_TRI="2", WDPM_RELAY="0", WDPM_TRI_K="2"),

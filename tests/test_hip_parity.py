@@ -189,6 +189,49 @@ def test_a_rough_dem_uploaded_over_a_smooth_one_inherits_no_16_bit_offsets(hip, 
             assert n_bit_diff(g.download_water(), o.download_water()) == 0
 
 
+@pytest.mark.parametrize("R,C,chunk", [(60, 400, 12), (33, 190, 0), (150, 700, 30)])
+def test_drain_on_codes_with_nodata_around_the_outlet(hip, oracle, R, C, chunk):
+    """ADVICE r4: the drain kernels stream the DEM codes too, and a NODATA code decodes to NaN, not +inf (wdpm_stencil.h::dem32_decode_nan
+    has the argument why both behave alike).  Here NODATA sits where each branch of that argument is exercised: cells that are
+    centres and neighbours all over the raster, a ring of NODATA on three sides of the outlet and one directly above it - with
+    the codes forced on launches of this size (32-bit and 16-bit), against the oracle on the fp64 DEM"""
+    rng = np.random.default_rng(R * 7 + C)
+    miss = -99999.0
+    y, x = np.mgrid[0:R, 0:C]
+    dem = np.round(500.0 + 0.2 * np.sin(x / 4.7) * np.cos(y / 3.1) + rng.normal(0, 0.03, (R, C)) + 0.003 * ((x - C // 2) ** 2 + (y - R // 2) ** 2) ** 0.5, 4)
+    dem[rng.random((R, C)) < 0.06] = miss
+    r0, c0 = R // 2, C // 2
+    dem[r0, c0] = 495.0                                     # the outlet: the lowest valid cell by far (5 m: its group of 48 columns still fits 16-bit offsets)
+    dem[r0 - 1, c0] = miss                                  # NODATA straight above it,
+    dem[r0 + 1, c0 - 1:c0 + 2] = miss                       # below it
+    dem[r0 - 1:r0 + 2, c0 + 1] = miss                       # and to its right: it can be reached from the left and the upper left only
+    dem[r0, c0 - 1], dem[r0 - 1, c0 - 1] = 499.5, 499.6
+    water = np.where(dem > miss, 0.05 + 0.2 * rng.random((R, C)), 0.0)
+    bd, bw = pad(dem, water, miss)
+    dr, dc = find_drain(bd)
+    assert (dr, dc) == (r0 + 1, c0 + 1)
+    kw = dict(module="drain", nrows=R, ncols=C, missingvalue=miss, drainrow=dr, draincol=dc)
+    td0 = max(bw[dr, dc], 0.0)
+    with oracle.context(**kw) as o:
+        o.upload(bd, bw)
+        o.totaldrain = td0
+        o.iterate(9)
+        want = (o.run_block(16, 1e-5), o.download_water(), o.totaldrain)
+    assert want[2] > td0                                    # water did reach the outlet
+    for d16 in (0, 1):
+        with hip.context(kernel=wdpm_amd.KERNEL_FUSED, chunk_rows=chunk, **kw) as g:
+            g.upload(bd, bw)
+            g.totaldrain = td0
+            g.set_option(wdpm_amd.OPT_DEM32, 2)
+            g.set_option(wdpm_amd.capi.OPT_DEM16, d16)
+            assert g.get_option(wdpm_amd.OPT_DEM32) == 1
+            if d16 and os.environ.get("WDPM_DEM16", "1") != "0":
+                assert g.get_option(wdpm_amd.capi.OPT_DEM16) == 1
+            g.iterate(9)
+            md = g.run_block(16, 1e-5)
+            assert n_bit_diff(g.download_water(), want[1]) == 0 and md == want[0] and g.totaldrain == want[2], d16
+
+
 def test_dem_codes_are_refused_for_non_decimal_elevations(hip, oracle):
     _compare_with_oracle(hip, oracle, "add", 60, 400, seed=77, iters=(5,), kernel=wdpm_amd.KERNEL_FUSED, dem32=1,
                          dem_digits=None)

@@ -188,8 +188,8 @@ def test_config_4_settling(hip, golden, tag, devices, fp64dem, iters):
 @pytest.mark.parametrize("tag,devices,fp64dem", VARIANTS, ids=[v[0] for v in VARIANTS])
 def test_config_5_drain_from_the_settled_add_state(hip, golden, tag, devices, fp64dem):
     z, idx = golden
-    need(idx, "cfg5_add_8192_i1000", "cfg5_drain_8192_a1000_d100", "cfg5_drain_8192_a1000_d1000")
-    job_config5(hip, z, idx, devices, fp64dem)
+    need(idx, "cfg5_add_8192_i1000", "cfg5_drain_8192_a1000_d100")
+    job_config5(hip, z, idx, devices, fp64dem, upto=[k for k in (100, 1000) if f"cfg5_drain_8192_a1000_d{k}" in idx])
 
 
 @pytest.mark.parametrize("tag,devices,fp64dem", VARIANTS, ids=[v[0] for v in VARIANTS])
@@ -218,7 +218,7 @@ def test_settled_jobs_over_the_standin_rccl(hip, golden):
                PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "tests"), os.environ.get("PYTHONPATH", "")]))
     p = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
-    for tag, names in (("cfg3", ["cfg3_add_4096_b2_i2000"]), ("cfg4", ["cfg4_add_16384_i100"]), ("cfg5", ["cfg5_drain_8192_a1000_d1000"]),
+    for tag, names in (("cfg3", ["cfg3_add_4096_b2_i2000"]), ("cfg4", ["cfg4_add_16384_i100"]), ("cfg5", ["cfg5_drain_8192_a1000_d100"]),
                        ("cfg3x", ["cfg3x_ponds_4096_b2_i400"])):
         if all(n in idx for n in names):
             assert f"SETTLED_RCCL_OK {tag}" in p.stdout, p.stdout
@@ -235,8 +235,8 @@ if __name__ == "__main__" and os.environ.get("WDPM_SETTLED_WORKER"):
     if "cfg4_add_16384_i100" in _idx:
         job_one_block(_hip, _z, _idx["cfg4_add_16384_i100"], _dev)
         print("SETTLED_RCCL_OK cfg4", flush=True)
-    if "cfg5_drain_8192_a1000_d1000" in _idx:
-        assert wdpm_amd.HALO_NAMES[job_config5(_hip, _z, _idx, _dev)] == "rccl"
+    if "cfg5_drain_8192_a1000_d100" in _idx:
+        assert wdpm_amd.HALO_NAMES[job_config5(_hip, _z, _idx, _dev, upto=[k for k in (100, 1000) if f"cfg5_drain_8192_a1000_d{k}" in _idx])] == "rccl"
         print("SETTLED_RCCL_OK cfg5", flush=True)
     if "cfg3x_ponds_4096_b2_i400" in _idx:
         job_two_blocks(_hip, _z, _idx, "cfg3x_ponds_4096_i200", "cfg3x_ponds_4096_b2_i400", _dev, water=ponds)

@@ -22,6 +22,9 @@ if module == "drain":
     k = int(np.argmin(np.where(bd > 0, bd, np.inf))); kw = dict(drainrow=k // (C + 2), draincol=k % (C + 2))
 with lib.context(module=module, nrows=R, ncols=C, missingvalue=-99999.0, kernel=wdpm_amd.KERNEL_FUSED, **kw) as c:
     c.upload(bd, bw); c.run_block(20, 0.0); c.iterate(int(os.environ.get('WT_WARM', '30'))); c.synchronize()
+    c.timing_reset(); c.iterate(100); c.synchronize()
+    period_us = c.timing()[1] / 100 * 1000          # launch to launch on the stream, this build, this box (HIP events around 100 iterations)
+    print(f"period of a launch on the stream: {period_us:.1f} us per iteration (compare with the spans below: the rest is dispatch, ramp and end-of-kernel)")
     for rep in range(3):
         c.iterate(5); c.synchronize()
         buf = np.zeros((8192, 4), dtype=np.uint64)
@@ -33,7 +36,8 @@ with lib.context(module=module, nrows=R, ncols=C, missingvalue=-99999.0, kernel=
         base = t0.min(); s = (t0 - base) / 100.0; e = (t1 - base) / 100.0   # us
         span = e.max()
         xcc = (t[:, 2] >> np.uint64(32)).astype(int) & 15
-        strip = (t[:, 3] >> np.uint64(32)).astype(int); chunk = (t[:, 3] & np.uint64(0xffffffff)).astype(int)
+        strip = (t[:, 3] >> np.uint64(48)).astype(int); chunk = (t[:, 3] & np.uint64(0xffffffff)).astype(int)
+        nst = ((t[:, 3] >> np.uint64(32)) & np.uint64(0xffff)).astype(int)       # marching steps of the wave (H / 3 + 2)
         dur = e - s
         print(f"== {R}x{C} {module}, launch {rep}: {n} waves ({strip.max()+1} strips x {chunk.max()+1} chunks), span {span:.1f} us")
         print("   starts  p50 %.1f  p90 %.1f  p99 %.1f  max %.1f us" % tuple(np.percentile(s, [50, 90, 99, 100])))
@@ -46,7 +50,15 @@ with lib.context(module=module, nrows=R, ncols=C, missingvalue=-99999.0, kernel=
         for x in range(8):
             m = xcc == x
             if m.any():
-                print("   XCD %d: %4d waves, median duration %.1f, last end %.1f us" % (x, m.sum(), np.median(dur[m]), e[m].max()))
+                print("   XCD %d: %4d waves, median duration %.1f, mean %.1f, last end %.1f us; steps per wave mean %.2f (%s); us per step %.3f" %
+                      (x, m.sum(), np.median(dur[m]), dur[m].mean(), e[m].max(), nst[m].mean(), dict(zip(*np.unique(nst[m], return_counts=True))), dur[m].sum() / nst[m].sum()))
+        print("   balance:", c.balance_info())
+        # logical XCD of a work item (the kernel's remap: item -> workgroup vb -> XCD share vb // (grid / 8), grid a multiple of 8) against
+        # the physical one it ran on: a constant difference = the dispatcher's round-robin started at another XCD in this launch
+        item = np.nonzero(buf[:, 1] > 0)[0]; wpb = 8 if len(np.unique(slot)) > 1 else 4
+        grid = ((int(item.max()) + wpb) // wpb + 7) // 8 * 8
+        rot = (xcc - (item // wpb) // (grid // 8)) % 8
+        print("   physical - logical XCD (mod 8):", dict(zip(*np.unique(rot, return_counts=True))))
         # per SIMD (XCD, the hardware id above the SIMD bits, SIMD): how many waves it held, when its last one ended - a launch of one
         # resident round ends with its busiest SIMD (round 5: tall chunks paired with short ones per SIMD)
         hw = (t[:, 2] & np.uint64(0xffffffff)).astype(np.int64)

@@ -195,6 +195,9 @@ def _preload_torch_hip_runtime():
         pass
 
 
+_SINCE_ROUND_5 = {"wdpm_device_info"}
+
+
 class Lib:
     """A loaded shared library exporting the wdpm C ABI."""
 
@@ -205,6 +208,8 @@ class Lib:
         _preload_torch_hip_runtime()
         self.dll = C.CDLL(path)
         for name, (res, args) in SYMBOLS.items():
+            if name in _SINCE_ROUND_5 and os.path.basename(path).startswith("alt_") and not hasattr(self.dll, name):
+                continue                  # an A/B build of an earlier revision (tools/build_alt.sh): timing runs do not call these
             fn = getattr(self.dll, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args

@@ -311,13 +311,13 @@ int wdpm_create(wdpm_ctx **out, const wdpm_params *p) {
     if (x->bal.mode < 0 || x->bal.mode > 2) x->bal.mode = 1;
     x->bal.capacity = 16384;
     if (x->bal.mode) {
-      static const float even[9] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 0.95f};
-      static const float skew[9] = {0.8f, 1.2f, 0.9f, 1.1f, 1.25f, 0.75f, 1.0f, 1.0f, 0.8f};
+      static const float even[kBalClasses] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 0.95f, 1.f};
+      static const float skew[kBalClasses] = {0.8f, 1.2f, 0.9f, 1.1f, 1.25f, 0.75f, 1.0f, 1.0f, 0.8f, 1.15f};
       e = hipMalloc(&x->bal.table, (size_t)x->bal.capacity * sizeof(int));
-      if (e == hipSuccess) e = hipMalloc(&x->bal.acc, 18 * sizeof(unsigned long long));
-      if (e == hipSuccess) e = hipMalloc(&x->bal.weight, 9 * sizeof(float));
-      if (e == hipSuccess) e = hipMemsetAsync(x->bal.acc, 0, 18 * sizeof(unsigned long long), x->stream);
-      if (e == hipSuccess) e = hipMemcpyAsync(x->bal.weight, x->bal.mode == 2 ? skew : even, 9 * sizeof(float), hipMemcpyHostToDevice, x->stream);
+      if (e == hipSuccess) e = hipMalloc(&x->bal.acc, (2 * kBalClasses + 2) * sizeof(unsigned long long));
+      if (e == hipSuccess) e = hipMalloc(&x->bal.weight, kBalClasses * sizeof(float));
+      if (e == hipSuccess) e = hipMemsetAsync(x->bal.acc, 0, (2 * kBalClasses + 2) * sizeof(unsigned long long), x->stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(x->bal.weight, x->bal.mode == 2 ? skew : even, kBalClasses * sizeof(float), hipMemcpyHostToDevice, x->stream);
     }
   }
   {

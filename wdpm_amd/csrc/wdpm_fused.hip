@@ -341,10 +341,21 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
   // speed matter, never correctness): give each XCD a contiguous run of work items so that the
   // halo columns shared by neighbouring strips hit in its L2 (+2 % measured).  gridDim.x is a
   // multiple of 8, so b -> (b % 8) * (gridDim.x / 8) + b / 8 is a permutation of the blocks.
+  // ... and the share a workgroup takes is that of the PHYSICAL XCD it is expected to run on (BalanceArgs::rot): blockIdx % 8 turned by
+  // the rotation the previous launch observed - one value for the whole launch, so this stays a permutation of the blocks.
+  const int xcc_phys = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7);          // XCC_ID
+  int rot_prev = 0;
+  if (bal.rot) {
+    rot_prev = __builtin_amdgcn_readfirstlane((int)(bal.rot[bal.parity] & 7));
+    if (blockIdx.x == 0 && threadIdx.x == 0) bal.rot[bal.parity ^ 1] = (unsigned long long)xcc_phys;   // workgroup 0's XCD = this launch's rotation
+  }
+  const int share = (int)((blockIdx.x + (unsigned)rot_prev) % 8);
 #ifdef WDPM_XCD_REVERSE   /* timing experiments: XCD x takes the raster's band 7 - x (does a slow XCD stay slow, or the band?) */
-  const int vb = (7 - blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8;
+  const int vb = (7 - share) * (gridDim.x / 8) + blockIdx.x / 8;
+#elif defined(WDPM_ORDER_REVERSE)   /* timing experiments: an XCD's workgroups take its band from the bottom up (is it the first rows of the raster that are slow, or the workgroups dispatched first?) */
+  const int vb = share * (gridDim.x / 8) + (gridDim.x / 8 - 1 - blockIdx.x / 8);
 #else
-  const int vb = (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8;
+  const int vb = share * (gridDim.x / 8) + blockIdx.x / 8;
 #endif
   // the wave number is the same in all 64 lanes: say so, and everything derived from it (strip,
   // chunk, row bases, loop bounds) lives in SGPRs and is computed on the scalar unit
@@ -501,7 +512,21 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
   // Only waves of the last strip / last chunk can touch cells outside the slab; every other wave
   // loads without any predicate.  `edge` is wave-uniform (the margin lets interior waves prefetch
   // past their last step unconditionally).
+  // Round 5: a strip that reaches past the raster's right edge is NOT an edge case.  Its lanes beyond column ncp - 1 hold whatever
+  // the clamped loads bring - the border cell and the first cells of the next row - and never touch the raster: column ncp - 1 is the
+  // reference's 1-cell border (bigdem = missingvalue, WDPMCL.c:796-807; +inf / NaN here), which neither gives (its centre test fails;
+  // in the gate-free variants its depth is +0.0, or they would not run) nor receives (as a neighbour dem + w is inf / NaN and the
+  // flow +-0), every path from a cell beyond the edge to a cell of the raster leads through it, and no lane beyond it is ever
+  // stored (the store columns are clamped to the border, which holds what it held).  The kernel relied on that border before - it
+  // runs centres on every column, the border's included.  Rounds 1 - 4 sent those waves down the masking instantiation of the
+  // marching loop: one wave per workgroup, alone on a code path nobody shared its instruction-cache misses with - they ended 3.5 %
+  // (8192^2 drain) to 12 % (the 8-GPU drain slab) after everybody else, the last waves of almost every launch
+  // (profiles/r05/first_chunk_row.txt, wave_times_coledge.txt).  -DWDPM_COL_EDGE_MASKS: as before (A/B).
+#ifdef WDPM_COL_EDGE_MASKS
   const bool edge = (c0 + kStripIn > g.ncp) || (A + 3 * (nsteps + 1) > g.rows);
+#else
+  const bool edge = (A + 3 * (nsteps + 1) > g.rows);
+#endif
   const size_t pitch = (size_t)g.ncp;
   // Cells a wave must not write (outside its exact output block) are redirected to a 64-double
   // dump area behind the raster instead of being branched around: the loop then issues the same
@@ -523,7 +548,7 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
     // row's first cells, or, in the slab's last row, the 192 spare cells behind every raster wdpm_create allocates (16 codes behind
     // the DEM codes) - and masks them on use, as it masks whole lanes beyond the raster.  (Rounds 1 - 3 clamped column by column:
     // nine loads per row instead of three, and the edge waves were the last of every launch to end, round 4.)
-    const int voff0 = 8 * (EDGE ? (colb < g.ncp ? colb : g.ncp - 1) : colb);
+    const int voff0 = 8 * (colb < g.ncp ? colb : g.ncp - 1);      // loop-invariant: the clamp costs the interior waves nothing
     const int qoff0 = voff0 / 2;                     // the same for the 4-byte dem codes,
     const int hoff0 = voff0 / 4;                     // the 2-byte offsets
     const int goff0 = 4 * ((voff0 / 8) / kDemGroup); // and the 4-byte group bases (one per kDemGroup columns)
@@ -730,7 +755,7 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
           any_lo |= (unsigned)__double2loint(W[i][j]);
           any_hi |= (unsigned)__double2hiint(W[i][j]);
         }
-      nzmask |= __ballot((any_lo | any_hi) != 0);
+      nzmask |= __ballot(((any_lo | any_hi) != 0) & (colb < g.ncp));      // (lanes beyond the raster's right edge hold other rows' cells)
       __builtin_amdgcn_wave_barrier();
       if (use_prio) {
         const int p = __builtin_amdgcn_readfirstlane(partner_at);
@@ -795,9 +820,12 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
   if (bal.acc && lane == 0) {
     // class 0 .. 7: the XCD (workgroups are dealt round-robin over them); class 8: the waves of a strip's last chunk, whatever
     // their XCD - they take the clamping loads and the masks of the slab's lower edge on every step and end ~5 % late
-    const int x = chunk == tf.nchunks - 1 ? 8 : (int)(blockIdx.x & 7);
-    atomicAdd(bal.acc + x, wall_clock64() - bal_t0);
-    atomicAdd(bal.acc + 9 + x, 1ull);
+    // (with `rot`: by physical XCD, and only where the share this workgroup took is the one sized for the XCD it ran on)
+    const int x = chunk == tf.nchunks - 1 ? 8 : chunk == 0 ? 9 : (bal.rot ? xcc_phys : (int)(blockIdx.x & 7));
+    if (!bal.rot || share == xcc_phys) {
+      atomicAdd(bal.acc + x, wall_clock64() - bal_t0);
+      atomicAdd(bal.acc + kBalClasses + x, 1ull);
+    }
   }
 #ifdef WDPM_WAVE_TIMES
   if (lane == 0 && item < 8192) {
@@ -805,7 +833,7 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
     g_wave_times[4 * item] = wt0;
     g_wave_times[4 * item + 1] = wall_clock64();
     g_wave_times[4 * item + 2] = __builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);  // HW_ID, XCC_ID
-    g_wave_times[4 * item + 3] = ((unsigned long long)strip << 32) | (unsigned)chunk;
+    g_wave_times[4 * item + 3] = ((unsigned long long)strip << 48) | ((unsigned long long)(nsteps & 0xffff) << 32) | (unsigned)chunk;   /* (the marching kernel) */
   }
 #endif
 }
@@ -1405,22 +1433,22 @@ __global__ void __launch_bounds__(256)
 xcd_rebalance_kernel(float *__restrict__ weight, unsigned long long *__restrict__ acc, int *__restrict__ table, const int nstrips,
                      const int nchunks, const int A0, const int out_last, const int ipx, const int update, const int from_uniform,
                      const int pair) {
-  __shared__ float w[9];
+  __shared__ float w[kBalClasses];
   if (threadIdx.x == 0) {
-    float mean[9], m = 0.f;
+    float mean[kBalClasses], m = 0.f;
     bool all = true;
-    for (int x = 0; x < 9; x++) {
+    for (int x = 0; x < kBalClasses; x++) {
       const float v = weight[x];
       w[x] = (v > 0.5f && v < 2.0f) ? v : 1.0f;
-      const unsigned long long n = acc[9 + x];
+      const unsigned long long n = acc[kBalClasses + x];
       mean[x] = n ? (float)((double)acc[x] / (double)n) : 0.f;
       if (x < 8) { all = all && n > 0 && mean[x] > 0.f; m += mean[x]; }
     }
     if (update && all) {
       m *= 0.125f;
       float sum = 0.f;
-      for (int x = 0; x < 9; x++) {
-        if (x == 8 && !(mean[8] > 0.f)) break;
+      for (int x = 0; x < kBalClasses; x++) {
+        if (x >= 8 && !(mean[x] > 0.f)) continue;            // (a launch of two chunk rows has no waves in a class of its own)
         const float base = from_uniform ? 1.0f : w[x];
         float r = m / mean[x];                               // > 1: these waves end early, they can take taller chunks
         r = r < 0.8f ? 0.8f : (r > 1.25f ? 1.25f : r);
@@ -1431,15 +1459,15 @@ xcd_rebalance_kernel(float *__restrict__ weight, unsigned long long *__restrict_
         const float v = w[x] * 8.0f / sum;
         w[x] = v < 0.7f ? 0.7f : (v > 1.4f ? 1.4f : v);
       }
-      w[8] = w[8] < 0.75f ? 0.75f : (w[8] > 1.2f ? 1.2f : w[8]);
+      for (int x = 8; x < kBalClasses; x++) w[x] = w[x] < 0.75f ? 0.75f : (w[x] > 1.2f ? 1.2f : w[x]);
     }
-    for (int x = 0; x < 9; x++) { weight[x] = w[x]; acc[x] = 0; acc[9 + x] = 0; }
+    for (int x = 0; x < kBalClasses; x++) { weight[x] = w[x]; acc[x] = 0; acc[kBalClasses + x] = 0; }
   }
   __syncthreads();
   const int T = (out_last - 1 - A0 + 2) / 3;                 // row triples the chunks of a strip share: A0 + 3 T >= out_last - 1
   auto wgt = [&](const int c, const int s) {
     const int x = (c * nstrips + s) / ipx;
-    return w[x < 7 ? x : 7] * (c == nchunks - 1 ? w[8] : 1.0f);
+    return w[x < 7 ? x : 7] * (c == nchunks - 1 ? w[8] : c == 0 ? w[9] : 1.0f);
   };
   for (int s = (int)threadIdx.x; s < nstrips; s += (int)blockDim.x) {
     float total = 0.f;
@@ -1780,7 +1808,7 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
   // Chunk heights by what each XCD delivers (wdpm_kernels.h::XcdBalance): whole-slab launches of two waves per SIMD that keep no
   // dry-tile flags.  Every launch may be measured (the block's first and last are other instantiations: not those); the table
   // needs chunks of a dozen rows at least, so that whole row triples can follow weights a few per cent apart.
-  BalanceArgs ba{nullptr, nullptr};
+  BalanceArgs ba{nullptr, nullptr, nullptr, 0};
   const bool bal_forced = bal && bal->mode == 2;          /* tests: the table on launches of any size, from skewed weights */
   if (bal && bal->mode && (two_per_simd || bal_forced) && A0 == 0 && out_last == g.rows - 1 && (chunk_rows < 3 || bal_forced) && nchunks >= 2) {
     const bool can_table = !tf.zout && H >= (bal_forced ? 6 : 12) && (nchunks + 1) * nstrips <= bal->capacity;
@@ -1790,10 +1818,12 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
     // xcd_rebalance_kernel).  WDPM_PAIR=0: round 4's geometry (A/B, tests).
     static std::atomic<int> env_pair{-1};
     if (env_pair < 0) { const char *t = getenv("WDPM_PAIR"); env_pair = t ? atoi(t) : 1; }
-    const int pair = (wpb == 8 && !bal_forced && env_pair.load(std::memory_order_relaxed) != 0) ? 1 : 0;
+    // (WDPM_PAIR=2, tests: also on forced tables and launches of one wave per SIMD, down to the table's minimum of two triples a chunk)
+    const int pair_mode = env_pair.load(std::memory_order_relaxed);
+    const int pair = ((wpb == 8 && !bal_forced && pair_mode != 0) || pair_mode == 2) ? 1 : 0;
     if (can_table && pair) {
       const int T = (out_last - 1 - A0 + 2) / 3, nc = slots / nstrips;
-      if (nc > nchunks && T / nc >= 4 && (nc + 1) * nstrips <= bal->capacity) {
+      if (nc > nchunks && T / nc >= (pair_mode == 2 ? 2 : 4) && (nc + 1) * nstrips <= bal->capacity) {
         nchunks = nc;
         nitems = nstrips * nchunks;
         grid = dim3(((nitems + wpb - 1) / wpb + 7) / 8 * 8);
@@ -1814,6 +1844,12 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
         if (update) bal->updates++;
       }
       ba.table = bal->table;
+      static std::atomic<int> env_rot{-1};         // WDPM_ROT=0: shares and measurements by blockIdx % 8, as in round 4 (A/B)
+      if (env_rot < 0) { const char *t = getenv("WDPM_ROT"); env_rot = t ? atoi(t) : 1; }
+      if (env_rot.load(std::memory_order_relaxed) != 0) {
+        ba.rot = bal->acc + 2 * kBalClasses;          // shares and measurements by physical XCD (BalanceArgs::rot)
+        ba.parity = bal->seq++ & 1;
+      }
       // measured: while the weights are young, every steady launch (an update every three); afterwards three launches in 256
       if (steady && (bal->updates < 6 || (bal->launches & 255) < 3)) {
         if (bal->measured == 0 || !bal->measured_uniform) { ba.acc = bal->acc; bal->measured_uniform = 0; bal->measured++; }
@@ -1822,6 +1858,8 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
     } else if (steady && bal->updates == 0 && H >= 12 && (bal->measured == 0 || bal->measured_uniform)) {
       // equal heights (a block that keeps dry-tile flags): what the XCDs deliver can be learnt here already
       ba.acc = bal->acc;
+      ba.rot = bal->acc + 2 * kBalClasses;
+      ba.parity = bal->seq++ & 1;
       bal->measured_uniform = 1;
       bal->measured++;
     }

@@ -32,10 +32,18 @@ __device__ __forceinline__ double dem32_decode(const int q, const double k0, con
 }
 
 /* The same for the iteration kernels, one instruction shorter: a NODATA code comes out as a NaN (only the high word is replaced)
- * instead of +inf.  Every use of an elevation in the add / subtract kernels - the only ones that stream codes - treats the two
- * alike: as a neighbour, dem + w is NaN / inf, ht is NaN / -inf and nothing moves; as a centre, `dem < inf` is false (the gate,
- * the max-diff validity test), and in the gate-free variants the centre depth is +0.0 and the flow comes out as 0 through
- * `NaN > en` = false, x = ht = NaN, max(NaN / 8, -0.0) = -0.0 (clamped: +0.0). */
+ * instead of +inf.  Every use of an elevation in the kernels that stream codes treats the two alike.
+ * add / subtract (flow_add_nz): as a neighbour, dem + w is NaN / inf, ht is NaN / -inf and nothing moves; as a centre, `dem < inf` is
+ * false (the gate, the max-diff validity test), and in the gate-free variants the centre depth is +0.0 and the flow comes out as 0
+ * through `NaN > en` = false, x = ht = NaN, max(NaN / 8, -0.0) = -0.0 (clamped: +0.0).
+ * drain (flow_drain_nz; it streams the codes since late in round 4, ADVICE r4 asked for the argument): NaN NEIGHBOUR - nwe, ht, s and
+ * big = ldexp(ht) are NaN, m = v_min(NaN, NaN) = NaN, `dem_c > nwe` is false, x = m = NaN and f = max(NaN / 8, -0.0) = -0.0 (v_max
+ * returns its other operand; clamped: NaN -> +0.0): no transfer, as with +inf (nwe = inf, ht = s = big = m = -inf, f = -0.0).  NaN
+ * CENTRE - gated variants: `d11 < inf` is false, the centre runs as -inf with a local depth of 0; gate-free variants: its depth is +0.0
+ * exactly, ht, s, big, m are NaN, `NaN > nwe` is false, x = NaN, f = +-0.  The OUTLET's sink tests `dn < inf` (false for NaN as for
+ * +inf: a NODATA cell is never drained into) and the outlet itself is found among cells with dem > 0 on the fp64 DEM, never on the
+ * codes; drain()'s owed sum reads the fp64 DEM.  tests/test_hip_parity.py::test_drain_on_codes_with_nodata_around_the_outlet puts
+ * NODATA at a centre, at a neighbour and on three sides of the outlet and forces the codes on the marching and the relay kernel. */
 __device__ __forceinline__ double dem32_decode_nan(const int q, const double k0, const double D, const double rD) {
   const double n = (double)q + k0;
   const double q0 = n * rD;
