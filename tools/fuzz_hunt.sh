@@ -20,3 +20,7 @@ for t in "tests/test_hip_parity.py -k random_call" "tests/test_rowblock.py -k hi
   env $b WDPM_DEM32=2 WDPM_RELAY=0 WDPM_TRI=0 WDPM_FUZZ_SEEDS=$lo:$hi timeout -k 10 900 python -m pytest $t -m gpu -q -x 2>&1 | tail -n 3
   WDPM_PLAIN=0 WDPM_CLAMP=0 WDPM_PRIO=0 WDPM_DEM16=0 WDPM_RELAY=0 WDPM_TRI=0 WDPM_FUZZ_SEEDS=$lo:$hi timeout -k 10 900 python -m pytest $t -m gpu -q -x 2>&1 | tail -n 3
 done
+echo "== (round 5) the marching kernel alone with every slot of the resident round filled and partner strips rounded half a triple apart (WDPM_BALANCE=2 WDPM_PAIR=2)"
+for t in "tests/test_hip_parity.py -k random_call" "tests/test_rowblock.py -k hip_random_group" "tests/test_hip_parity.py -k every_"; do
+  WDPM_BALANCE=2 WDPM_PAIR=2 WDPM_RELAY=0 WDPM_TRI=0 WDPM_FUZZ_SEEDS=$lo:$hi timeout -k 10 900 python -m pytest $t -m gpu -q -x 2>&1 | tail -n 3
+done
