@@ -25,6 +25,7 @@ with lib.context(module=module, nrows=R, ncols=C, missingvalue=-99999.0, kernel=
     c.timing_reset(); c.iterate(100); c.synchronize()
     period_us = c.timing()[1] / 100 * 1000          # launch to launch on the stream, this build, this box (HIP events around 100 iterations)
     print(f"period of a launch on the stream: {period_us:.1f} us per iteration (compare with the spans below: the rest is dispatch, ramp and end-of-kernel)")
+    prev_wg = None
     for rep in range(3):
         c.iterate(5); c.synchronize()
         buf = np.zeros((8192, 4), dtype=np.uint64)
@@ -70,6 +71,21 @@ with lib.context(module=module, nrows=R, ncols=C, missingvalue=-99999.0, kernel=
               (len(uk), (cnt == 1).sum(), (cnt == 2).sum(), (cnt > 2).sum(), *np.percentile(last_end, [10, 50, 90, 100]), np.median(tot), tot.max()))
         by_chunk = [round(float(np.median(dur[chunk == k])), 1) for k in range(chunk.max() + 1)]
         print("   median duration by chunk row:", by_chunk[:12], "..." if len(by_chunk) > 24 else "", by_chunk[12:] if len(by_chunk) <= 24 else by_chunk[-12:])
+        # is a slow workgroup slow again in the next launch (same table, same geometry)?  Mean duration per step of each workgroup's waves,
+        # this launch against the previous one looked at, and whether the workgroup sat on the same CU (hardware id above the wave-slot bits)
+        full = np.zeros(len(buf)); full[item] = dur / np.maximum(nst, 1)
+        hwfull = np.zeros(len(buf), dtype=np.int64); hwfull[item] = (xcc.astype(np.int64) << 32) | (hw >> 6)
+        nwg = (int(item.max()) + wpb) // wpb
+        per_wg = np.array([full[w * wpb:(w + 1) * wpb][full[w * wpb:(w + 1) * wpb] > 0].mean() if (full[w * wpb:(w + 1) * wpb] > 0).any() else 0.0 for w in range(nwg)])
+        cu_of = np.array([hwfull[w * wpb] for w in range(nwg)])
+        if prev_wg is not None and len(prev_wg[0]) == len(per_wg):
+            ok = (per_wg > 0) & (prev_wg[0] > 0)
+            same_cu = float((cu_of[ok] == prev_wg[1][ok]).mean())
+            r = float(np.corrcoef(per_wg[ok], prev_wg[0][ok])[0, 1])
+            rel = per_wg[ok] / np.median(per_wg[ok])
+            print("   workgroups: us per step  p5 %.3f  p50 %.3f  p95 %.3f  max %.3f (x median: %.3f .. %.3f); correlation with the previous launch looked at %.2f; on the same CU as then: %.0f %%" %
+                  (*np.percentile(per_wg[ok], [5, 50, 95, 100]), rel.min(), rel.max(), r, 100 * same_cu))
+        prev_wg = (per_wg, cu_of)
         last = np.argsort(e)[-8:]
         print("   last to end (strip, chunk, xcd, start, end):", [(int(strip[i]), int(chunk[i]), int(xcc[i]), round(float(s[i]), 1), round(float(e[i]), 1)) for i in last])
         first = np.argsort(e)[:4]
