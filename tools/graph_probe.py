@@ -9,7 +9,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import wdpm_amd
 R, Cc = int(sys.argv[1]), int(sys.argv[2]); module = sys.argv[3] if len(sys.argv) > 3 else "add"; K = int(sys.argv[4]) if len(sys.argv) > 4 else 48
 lib = wdpm_amd.load_hip()
-hip = C.CDLL("libamdhip64.so")
+hip = lib.dll            # the HIP runtime the library itself is bound to: dlsym on its handle searches its dependencies
+for _n in ("hipStreamCreate", "hipStreamBeginCapture", "hipStreamEndCapture", "hipGraphInstantiate", "hipGraphLaunch", "hipGraphExecDestroy", "hipGraphDestroy"):
+    getattr(hip, _n).restype = C.c_int
 def ck(e, what):
     if e != 0: raise SystemExit(f"{what} failed: hip error {e}")
 rng = np.random.default_rng(1)
