@@ -564,7 +564,7 @@ fused_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
       for (int i = 0; i < 3; i++) {
         int r = r0 + i;
         if (EDGE) r = r < g.rows ? r : g.rows - 1;
-#ifdef WDPM_ABLATE_HBM   /* timing experiments only (tools/hbm_ablation.sh): what the kernel costs when its rows come from / go to the caches
+#ifdef WDPM_ABLATE_HBM   /* timing experiments only (tools/build_variant.sh ablateN -DWDPM_ABLATE_HBM=N, then tools/ab_interleaved.sh): what the kernel costs when its rows come from / go to the caches
                             instead of HBM.  Bits: 1 = the water loads come from the raster's first 48 rows, 2 = the stores land there,
                             4 = the DEM loads come from there.  Same instructions, same number of memory operations, wrong results. */
         const int rw = (WDPM_ABLATE_HBM & 1) ? r % 48 : r, rdm = (WDPM_ABLATE_HBM & 4) ? r % 48 : r;
