@@ -25,6 +25,7 @@ reference executable, serial path cpu=0), and writes DATA only:
     python tests/golden/make_golden.py [full]      ("full": only full_size.npz's early-state entries)
     python tests/golden/make_golden.py settled cfg3|cfg4|cfg5|cfg4long   (one process each, minutes to hours of a core)
     python tests/golden/make_golden.py merge       (fold the settled parts into full_size.npz)
+    python tests/golden/make_golden.py synthcli    (synth_cli.json: the reference EXECUTABLE's add / drain / subtract chain on a synthetic 3072^2 DEM)
 """
 import ctypes as C
 import gzip
@@ -262,6 +263,37 @@ def make_basin5_cli():
         json.dump(res, f, indent=1)
 
 
+def make_synth_cli(n=3072):
+    """The validation chain (validation/validate_WDPM.sh: add, drain, subtract) of the REFERENCE EXECUTABLE on a synthetic n x n DEM -
+    a size at which the product's marching kernel runs (basin5 is relay-kernel sized): report lines, summary and the sha256 of each
+    output raster.  The DEM is wdpm_synth_dem(n, seed n) written with four decimals; limits of 1000 / 1000 / 1000 iterations keep the
+    reference at about six minutes a step.  -> synth_cli.json"""
+    sys.path.insert(0, ROOT)
+    import wdpm_amd
+    gen = wdpm_amd.load(os.path.join(ROOT, "oracle", "_build", "libwdpm_oracle.so"))
+    res = {"n": n}
+    with tempfile.TemporaryDirectory() as td:
+        dem = gen.synth_dem(n, n)
+        with open(os.path.join(td, "dem.asc"), "w") as f:
+            f.write(f"ncols {n}\nnrows {n}\nxllcorner 0\nyllcorner 0\ncellsize 10\nNODATA_value -99999\n")
+            np.savetxt(f, dem, fmt="%.4f")
+        res["dem_sha256_of_values"] = hashlib.sha256(np.ascontiguousarray(dem).tobytes()).hexdigest()
+
+        def record(key, args, outfile):
+            rc, text = run_cli(args, td)
+            blocks, summary = parse_report(text)
+            res[key] = dict(args=[str(a) for a in args], rc=rc, blocks=blocks, summary=summary,
+                            out_sha256=file_sha(os.path.join(td, outfile)),
+                            report_sha256_nontiming=hashlib.sha256(strip_timing(text).encode()).hexdigest())
+            print(key, rc, blocks, summary, flush=True)
+
+        record("add100", ["add", "dem.asc", "NULL", "a.asc", "NULL", 100, 1.0, 1.0, 0, 0, 0.005, 1000], "a.asc")
+        record("drain", ["drain", "dem.asc", "a.asc", "d.asc", "NULL", 0.1, 1.0, 0, 0, 0.005, 1000], "d.asc")
+        record("sub10", ["subtract", "dem.asc", "d.asc", "s.asc", "NULL", 10, 1.0, 0, 0, 0.005, 1000], "s.asc")
+    with open(os.path.join(HERE, "synth_cli.json"), "w") as f:
+        json.dump(res, f, indent=1)
+
+
 def strip_timing(text):
     """Report text with the run-time column / Run Time line removed (they are wall-clock)."""
     out = []
@@ -494,6 +526,9 @@ def main():
         return
     if len(sys.argv) > 2 and sys.argv[1] == "settled":
         make_settled(load_ref(), sys.argv[2])
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "synthcli":
+        make_synth_cli()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "merge":
         merge_settled()

@@ -12,6 +12,7 @@ import shutil
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 from conftest import GOLDEN, ROOT
@@ -314,3 +315,27 @@ def test_hip_cli_report_backend_line_and_gdaldem_handoff(workdir, golden):
     """the same on the SHIPPED binary (wdpm_amd/bin/WDPMCL, HIP path): the helper that runs gdaldem is forked before
     anything touches the GPU - a process that has initialised it must not exec another program on this pool"""
     backend_line_and_gdaldem_handoff(HIP_CLI, "hip-gfx950", workdir, golden)
+
+
+@pytest.mark.gpu
+def test_hip_cli_chain_on_a_synthetic_dem_of_marching_kernel_size(tmp_path, hip):
+    """round 5: the validation chain (add 100 mm -> drain -> subtract 10 mm, 1000 iterations each) of the shipped binary on a synthetic
+    3072^2 DEM against what the REFERENCE EXECUTABLE printed and wrote for the same files (tests/golden/synth_cli.json, generated by
+    tests/golden/make_golden.py synthcli: about 20 minutes of the reference).  basin5, the reference's own sample, is a relay-kernel
+    raster here; this one takes the ArcASCII reader, the set-up on the device, the marching kernel (two waves per SIMD, DEM codes, XCD
+    balance), the drain module's outlet and bookkeeping, the statistics and the writer through one command line at a size where
+    that kernel runs by itself: report (minus wall clock) and rasters byte-identical."""
+    path = os.path.join(GOLDEN, "synth_cli.json")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/synth_cli.json has not been generated (tests/golden/make_golden.py synthcli)")
+    with open(path) as f:
+        g = json.load(f)
+    n = g["n"]
+    dem = hip.synth_dem(n, n)
+    assert hashlib.sha256(np.ascontiguousarray(dem).tobytes()).hexdigest() == g["dem_sha256_of_values"]
+    with open(tmp_path / "dem.asc", "w") as f:
+        f.write(f"ncols {n}\nnrows {n}\nxllcorner 0\nyllcorner 0\ncellsize 10\nNODATA_value -99999\n")
+        np.savetxt(f, dem, fmt="%.4f")
+    for key, outfile in (("add100", "a.asc"), ("drain", "d.asc"), ("sub10", "s.asc")):
+        err = check(HIP_CLI, g, key, tmp_path, outfile)
+        assert "hip-gfx950" in err
