@@ -20,7 +20,11 @@ bw = np.where(bd > -99999.0, 0.1, 0.0)
 kw = {}
 if module == "drain":
     k = int(np.argmin(np.where(bd > 0, bd, np.inf))); kw = dict(drainrow=k // (C + 2), draincol=k % (C + 2))
-with lib.context(module=module, nrows=R, ncols=C, missingvalue=-99999.0, kernel=wdpm_amd.KERNEL_FUSED, **kw) as c:
+row0 = int(os.environ.get("WT_ROW0", "0"))      # > 0 (a multiple of 3): the same rows as a MIDDLE slab of a taller raster - no NODATA border row on top
+if row0:
+    bd[0, 1:-1] = np.round(500 + rng.random(C), 4); bw[0, 1:-1] = 0.1; bd[-1, 1:-1] = np.round(500 + rng.random(C), 4); bw[-1, 1:-1] = 0.1
+    kw.update(slab_row0=row0, slab_rows=R + 2)
+with lib.context(module=module, nrows=(R + 2 * row0 if row0 else R), ncols=C, missingvalue=-99999.0, kernel=wdpm_amd.KERNEL_FUSED, **kw) as c:
     c.upload(bd, bw); c.run_block(20, 0.0); c.iterate(int(os.environ.get('WT_WARM', '30'))); c.synchronize()
     c.timing_reset(); c.iterate(100); c.synchronize()
     period_us = c.timing()[1] / 100 * 1000          # launch to launch on the stream, this build, this box (HIP events around 100 iterations)

@@ -1425,7 +1425,8 @@ relay_iteration_kernel(const double *__restrict__ win, double *__restrict__ wout
 }
 
 /* wdpm_kernels.h::XcdBalance: (update) move the weights towards equal mean wave durations - weight 0 .. 7: the relative height of
- * the chunks whose work items run on that XCD, weight 8: a factor on a strip's last chunk (its waves are the slab's lower edge);
+ * the chunks whose work items run on that XCD (the physical one: BalanceArgs::rot), weight 8: a factor on a strip's last chunk (its
+ * waves are the slab's lower edge and take the masking loop), weight 9: one on its first (round 5: the slab's first chunk row ends late);
  * `from_uniform`: the measured launches ran on equal heights, whatever the weights say - then rebuild the table of row boundaries
  * for the launch geometry given: per strip, heights in proportion to the weights of its chunks, in whole row triples, at least two
  * per chunk, the last boundary at the launch's last triple.  One workgroup; the sums are cleared for the next measurement. */
