@@ -652,9 +652,12 @@ def main():
         # VALU issue share as the counters gave it: a share of the kernel's cycles (instructions per launch are a property
         # of the binary, and the share does not depend on the clock of the profiled pass)
         valu = pmc.get("valu_issue_frac")
+        # `bound` names the roofline `achieved` / `peak` are priced against (the contract's "hbm" | "mfma": HBM - there is no contraction in
+        # this path); what the kernel actually runs into first, by the counters, is said beside it
         bound = "hbm"
+        limiter = None
         if valu and valu > (hbm_real if hbm_real is not None else moved / (iter_ms * 1e-3) / 1e9 / HBM_PEAK_GBS):
-            bound = "valu-issue (fp64; no MFMA in this path) ahead of hbm"
+            limiter = "fp64 VALU issue and the board's power cap, ahead of HBM (valu_issue_frac against hbm_real_frac; no MFMA in this path)"
         out = {
             "metric": (f"cell-updates/sec on Add module, {n}x{n} DEM" if args.module == "add" else
                        f"cell-updates/sec on Drain module, {n}x{n} DEM (BASELINE config 5)"),
@@ -683,7 +686,7 @@ def main():
                          # counter bytes / kernel time / 8 TB/s: what the memory system really carries
                          "hbm_real_frac": hbm_real,
                          # share of the kernel's cycles in which a SIMD issues a VALU instruction: the OTHER ceiling
-                         "valu_issue_frac": valu,
+                         "valu_issue_frac": valu, "limited_by": limiter,
                          "counters_source": (pmc.get("mismatch") or ("profiles/traffic.json <- " + str(pmc.get("source")))) if pmc else None,
                          # the counters' own run: the kernel they were read on, its duration there (profiled passes run at a
                          # lower clock) and the library build - the same as this one, or they would not be quoted
