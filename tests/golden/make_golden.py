@@ -25,6 +25,7 @@ reference executable, serial path cpu=0), and writes DATA only:
     python tests/golden/make_golden.py [full]      ("full": only full_size.npz's early-state entries)
     python tests/golden/make_golden.py settled cfg3|cfg4|cfg5|cfg4long   (one process each, minutes to hours of a core)
     python tests/golden/make_golden.py merge       (fold the settled parts into full_size.npz)
+    python tests/golden/make_golden.py verify-oracle   (the CPU restatement against config 3's settled entries: 20 minutes)
     python tests/golden/make_golden.py synthcli    (synth_cli.json: the reference EXECUTABLE's add / drain / subtract chain on a synthetic 3072^2 DEM)
 """
 import ctypes as C
@@ -294,6 +295,27 @@ def make_synth_cli(n=3072):
         json.dump(res, f, indent=1)
 
 
+def verify_oracle_settled():
+    """The CPU restatement (oracle/wdpm_oracle.c) against the SETTLED golden of config 3: two blocks of 1000 iterations at 4096^2, the
+    threshold flush between them - twenty minutes of one core, so not part of the test suite (which pins the oracle at 4096^2 x 20 and on
+    the small vectors); run when the goldens are made.  Prints True True per block (max diff, sha256 of the padded raster)."""
+    import time
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import wdpm_amd
+    orc = wdpm_amd.load(os.path.join(ROOT, "oracle", "_build", "libwdpm_oracle.so"))
+    z = np.load(os.path.join(HERE, "full_size.npz"))
+    idx = {m["name"]: m for m in json.loads(bytes(z["index_json"]).decode())}
+    n, missing, thres = 4096, -99999.0, 0.005 / 1000
+    bd, bw = pad(orc.synth_dem(n, n), np.full((n, n), 0.1), missing)
+    t = time.time()
+    with orc.context(module="add", nrows=n, ncols=n, missingvalue=missing) as c:
+        c.upload(bd, bw)
+        for name in ("cfg3_add_4096_i1000", "cfg3_add_4096_b2_i2000"):
+            md = c.run_block(1000, thres)
+            print(name, md == idx[name]["max_diff"], sha(c.download_water()) == idx[name]["sha256"], f"{time.time() - t:.0f} s", flush=True)
+
+
 def strip_timing(text):
     """Report text with the run-time column / Run Time line removed (they are wall-clock)."""
     out = []
@@ -526,6 +548,9 @@ def main():
         return
     if len(sys.argv) > 2 and sys.argv[1] == "settled":
         make_settled(load_ref(), sys.argv[2])
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "verify-oracle":
+        verify_oracle_settled()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "synthcli":
         make_synth_cli()
