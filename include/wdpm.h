@@ -364,12 +364,17 @@ int  wdpm_group_enqueue_stats(wdpm_group *grp, double *seconds, double *exchange
  *   are identical either way.  WDPM_OPT_TILES_SEEN / _WORKED (get): tiles of flag-keeping launches and those
  *   among them that did work, summed at every wdpm_max_diff.  WDPM_OPT_SPARSE (get/set): the kernel marches
  *   short chunks because most tiles were dry in the last block (the library switches by itself).
+ * WDPM_OPT_GRAPH_LAUNCHES (get; round 5): HIP graphs launched by wdpm_iterate so far.  Small rasters are launch-bound (basin5: 5.2 us of
+ *   kernel, 6.3 us from launch to launch queued one by one), so the iterations between a block's first and last launch are replayed as
+ *   graphs of 32 launches captured from the library's own loop - where a launch keeps no state on the host (the small-raster kernels)
+ *   and nobody times the launches.  WDPM_GRAPH=0 in the environment: never.  Results are identical either way.  The reference's
+ *   counterpart is nine blocking clEnqueueNDRangeKernel + clFinish pairs per iteration (WDPMCL.c:1155-1210).
  * WDPM_OPT_GUARD_BAD (get): with WDPM_GUARD_KB=<n> in the environment when the context was made, the big device buffers
  *   carry n KiB guard bands; this counts guard bytes that were overwritten (0 = no kernel wrote outside its buffer; always 0
  *   without the variable).  A debugging aid: the GPU pool has no address sanitizer. */
 enum { WDPM_OPT_SIGNED_ZERO_SAFE = 1, WDPM_OPT_DEM32 = 2, WDPM_OPT_TILES = 3, WDPM_OPT_TILES_SEEN = 4,
        WDPM_OPT_TILES_WORKED = 5, WDPM_OPT_SPARSE = 6, WDPM_OPT_GUARD_BAD = 7, WDPM_OPT_WATER_KINDS = 8,
-       WDPM_OPT_PLAIN_WATER = 9, WDPM_OPT_DEM16 = 10 };
+       WDPM_OPT_PLAIN_WATER = 9, WDPM_OPT_DEM16 = 10, WDPM_OPT_GRAPH_LAUNCHES = 11 };
 int wdpm_get_option(wdpm_ctx *ctx, int32_t key, int64_t *value);
 int wdpm_set_option(wdpm_ctx *ctx, int32_t key, int64_t value);
 

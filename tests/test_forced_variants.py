@@ -26,6 +26,7 @@ pytestmark = pytest.mark.gpu
 SUITE = ["tests/test_hip_parity.py::test_golden_stencil_vectors", "tests/test_hip_parity.py::test_random_rasters_match_oracle",
          "tests/test_hip_parity.py::test_dem_codes_on_and_off", "tests/test_hip_parity.py::test_dem_codes_as_16_bit_offsets_on_and_off",
          "tests/test_hip_parity.py::test_adversarial_operands", "tests/test_hip_parity.py::test_drain_on_codes_with_nodata_around_the_outlet",
+         "tests/test_hip_parity.py::test_steady_iterations_of_small_rasters_replayed_as_hip_graphs",
          "tests/test_hip_parity.py::test_drain_outlet_at_every_window_position", "tests/test_hip_parity.py::test_block_loop_matches_oracle",
          "tests/test_hip_parity.py::test_every_height_around_chunk_boundaries", "tests/test_hip_parity.py::test_every_width_around_strip_boundaries",
          "tests/test_hip_parity.py::test_negative_and_nan_inputs_are_handled_like_the_reference", "tests/test_hip_parity.py::test_degenerate_shapes",
@@ -39,7 +40,7 @@ VARIANTS = {
     "relay-everywhere-four-waves": dict(WDPM_RELAY="2", WDPM_RELAY_NW="4", WDPM_RELAY_PRIO="2"),
     "relay-everywhere-eight-waves-codes": dict(WDPM_RELAY="2", WDPM_RELAY_NW="8", WDPM_DEM32="2", WDPM_RELAY_PRIO="2"),
     "triangle-everywhere-six-rows": dict(WDPM_TRI="2", WDPM_RELAY="0", WDPM_TRI_K="2"),
-    "triangle-everywhere-three-rows-balance-off": dict(WDPM_TRI="2", WDPM_RELAY="0", WDPM_TRI_K="1", WDPM_BALANCE="0"),
+    "triangle-everywhere-three-rows-balance-off-no-graphs": dict(WDPM_TRI="2", WDPM_RELAY="0", WDPM_TRI_K="1", WDPM_BALANCE="0", WDPM_GRAPH="0"),
 }
 
 

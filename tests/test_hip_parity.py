@@ -232,6 +232,63 @@ def test_drain_on_codes_with_nodata_around_the_outlet(hip, oracle, R, C, chunk):
             assert n_bit_diff(g.download_water(), want[1]) == 0 and md == want[0] and g.totaldrain == want[2], d16
 
 
+@pytest.mark.parametrize("module", ["add", "subtract", "drain"])
+@pytest.mark.parametrize("R,C", [(120, 300), (482, 471), (61, 1000)])
+def test_steady_iterations_of_small_rasters_replayed_as_hip_graphs(hip, oracle, module, R, C):
+    """round 5: small rasters are launch-bound, so wdpm_iterate replays the iterations between a block's first and last launch as HIP
+    graphs of 32 launches captured from its own loop (include/wdpm.h: WDPM_OPT_GRAPH_LAUNCHES).  Same bits as the oracle through
+    counts on both sides of every threshold (33 iterations: none; 34: one graph; 35, 100, 131), through whole blocks (flush on the
+    first launch, max diff on the last), after an option change and a second upload into the same context (cached graphs carry what they
+    were given by value: they must go), and with the launches timed (no graphs then)"""
+    dem, water, miss = random_case(R * 31 + C, R, C)
+    bd, bw = pad(dem, water, miss)
+    kw = dict(module=module, nrows=R, ncols=C, missingvalue=miss)
+    td0 = 0.0
+    if module == "drain":
+        dr, dc = find_drain(bd)
+        td0 = max(bw[dr, dc], 0.0)
+        kw.update(drainrow=dr, draincol=dc)
+    graphs_on = os.environ.get("WDPM_GRAPH", "1") != "0"
+    with hip.context(**kw) as g, oracle.context(**kw) as o:
+        small = os.environ.get("WDPM_RELAY") != "0" or os.environ.get("WDPM_TRI") != "0"     # (a forced-variant suite may send every size to the marching kernel)
+        for c in (g, o):
+            c.upload(bd, bw)
+            c.totaldrain = td0
+        seen = 0
+        for n in (33, 34, 35, 100, 131):
+            g.iterate(n)
+            o.iterate(n)
+            assert n_bit_diff(g.download_water(), o.download_water()) == 0 and g.totaldrain == o.totaldrain, n
+            now = g.get_option(wdpm_amd.capi.OPT_GRAPH_LAUNCHES)
+            if graphs_on and small and os.environ.get("WDPM_RELAY") is None and os.environ.get("WDPM_TRI") is None:
+                assert now - seen == (n - 2) // 32, (n, now, seen)          # the first and the last iteration of a call are never in a graph
+            seen = now
+        for n, thres in ((200, 1e-5), (67, 2e-4)):
+            assert g.run_block(n, thres) == o.run_block(n, thres)
+            assert n_bit_diff(g.download_water(), o.download_water()) == 0 and g.totaldrain == o.totaldrain
+        g.set_option(wdpm_amd.OPT_DEM32, 2)                     # other codes in the launches from here on
+        g.iterate(70)
+        o.iterate(70)
+        assert n_bit_diff(g.download_water(), o.download_water()) == 0
+        dem2 = np.where(dem > miss, np.round(dem * 0.5 + 100.0, 3), dem)          # another DEM into the same context, same buffers
+        bd2, bw2 = pad(dem2, water * 0.5, miss)
+        if module == "drain":
+            dr, dc = find_drain(bd2)
+            for c in (g, o):
+                c.lib.check(c.lib.dll.wdpm_set_drain(c._h, dr, dc))
+        for c in (g, o):
+            c.upload(bd2, bw2)
+            c.totaldrain = 0.0
+            c.iterate(90)
+        assert n_bit_diff(g.download_water(), o.download_water()) == 0 and g.totaldrain == o.totaldrain
+        before = g.get_option(wdpm_amd.capi.OPT_GRAPH_LAUNCHES)
+        g.timing_reset()                                         # timed launches are queued one by one
+        g.iterate(80)
+        o.iterate(80)
+        assert g.get_option(wdpm_amd.capi.OPT_GRAPH_LAUNCHES) == before and g.timing()[0] == 80
+        assert n_bit_diff(g.download_water(), o.download_water()) == 0
+
+
 def test_dem_codes_are_refused_for_non_decimal_elevations(hip, oracle):
     _compare_with_oracle(hip, oracle, "add", 60, 400, seed=77, iters=(5,), kernel=wdpm_amd.KERNEL_FUSED, dem32=1,
                          dem_digits=None)

@@ -19,6 +19,7 @@ KERNEL_AUTO, KERNEL_PASS, KERNEL_FUSED = 0, 1, 2
 OPT_SIGNED_ZERO_SAFE = 1
 OPT_DEM32 = 2
 OPT_TILES, OPT_TILES_SEEN, OPT_TILES_WORKED, OPT_SPARSE, OPT_GUARD_BAD, OPT_WATER_KINDS, OPT_PLAIN_WATER, OPT_DEM16 = 3, 4, 5, 6, 7, 8, 9, 10
+OPT_GRAPH_LAUNCHES = 11
 HALO_AUTO, HALO_RCCL, HALO_PEER, HALO_HOST = 0, 1, 2, 3
 HALO_NAMES = {0: "none", 1: "rccl", 2: "peer", 3: "host"}
 COMM_ID_BYTES = 128

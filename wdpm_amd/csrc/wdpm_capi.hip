@@ -279,6 +279,7 @@ int wdpm_create(wdpm_ctx **out, const wdpm_params *p) {
   x->d_scal = nullptr; x->d_bits = nullptr; x->h_pin = nullptr; x->d_stat = nullptr;
   x->d_dem32 = nullptr; x->code = DemCode{nullptr, 0.0, 1.0, 1.0, 0, nullptr, nullptr, 0}; x->dem32_encodable = false; x->dem_bounded = false;
   x->d_dem16 = nullptr; x->d_gbase = nullptr; x->dem16_encodable = false; x->dem16_wanted = true;
+  x->graph_mode = -1; x->graph_launches = 0;
   x->d_sum_approx = nullptr; x->d_sum_i = nullptr; x->d_sum_k = nullptr; x->d_sum_flag = nullptr;
   x->own_stream = true;
   x->side = nullptr; x->ev_fork = nullptr; x->ev_join = nullptr; x->pending_join = false; x->ev_copy[0] = x->ev_copy[1] = nullptr;
@@ -352,6 +353,7 @@ void wdpm_destroy(wdpm_ctx *x) {
   if (x->ev_join) (void)hipEventDestroy(x->ev_join);
   for (int i = 0; i < 2; i++)
     if (x->ev_copy[i]) (void)hipEventDestroy(x->ev_copy[i]);
+  for (auto &ge : x->graphs) (void)hipGraphExecDestroy(ge.exec);
   for (auto &ep : x->pending) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
   for (auto &ep : x->pending_steady) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
   for (auto &ep : x->pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
@@ -419,10 +421,19 @@ static bool plain_water(const wdpm_ctx *x) {
   return env != 0 && !x->signed_zero_safe && !x->w_negative && !x->w_odd;
 }
 
+/* captured launches carry what they were given by value (wdpm_ctx::GraphEntry): a new DEM, other codes or another outlet end them */
+static void drop_graphs(wdpm_ctx *x) {
+  if (x->graphs.empty()) return;
+  (void)hipStreamSynchronize(x->stream);             /* a replay may still be running */
+  for (auto &ge : x->graphs) (void)hipGraphExecDestroy(ge.exec);
+  x->graphs.clear();
+}
+
 /* Try to express the DEM just uploaded as 32-bit codes k with dem == (k + k0) / 10^e bit for bit
  * (e = 0..6, the smallest that works; real DEMs are decimal text).  The device checks every cell
  * with the decoder the iteration kernel uses; any miss leaves the fp64 DEM in charge. */
 static int encode_dem(wdpm_ctx *x) {
+  drop_graphs(x);
   /* every level starts from "not encodable": a DEM uploaded over an earlier one inherits nothing (a smooth DEM, then a
    * rough one that passes only the 32-bit check, left dem16_encodable set and d_dem16 holding truncated offsets) */
   x->dem32_encodable = false; x->dem16_encodable = false; x->dem_bounded = false; x->dem16_wanted = true;
@@ -699,12 +710,14 @@ int wdpm_get_option(wdpm_ctx *x, int32_t key, int64_t *value) {
   else if (key == WDPM_OPT_TILES_SEEN) *value = x->stat_tiles;
   else if (key == WDPM_OPT_TILES_WORKED) *value = x->stat_active;
   else if (key == WDPM_OPT_SPARSE) *value = x->sparse ? 1 : 0;
+  else if (key == WDPM_OPT_GRAPH_LAUNCHES) *value = x->graph_launches;
   else if (key == WDPM_OPT_GUARD_BAD) return guard_damage(x, value);
   else return fail("wdpm_get_option: unknown option %d", key);
   return 0;
 }
 
 int wdpm_set_option(wdpm_ctx *x, int32_t key, int64_t value) {
+  drop_graphs(x);
   if (key == WDPM_OPT_SIGNED_ZERO_SAFE) {
     x->signed_zero_safe = value != 0;
   } else if (key == WDPM_OPT_WATER_KINDS) {        /* OR-ed in: what a multi-GPU driver found on the other ranks */
@@ -872,7 +885,7 @@ int wdpm_iterate(wdpm_ctx *x, int32_t n_iter) {
     if (!x->pool.empty()) { st = x->pool.back(); x->pool.pop_back(); }
     else { HIP_TRY(hipEventCreate(&st.a)); HIP_TRY(hipEventCreate(&st.b)); }
   }
-  for (int it = 0; it < n_iter; it++) {
+  auto one_iteration = [&](const int it) -> int {
     if (steady && it == 1) HIP_TRY(hipEventRecord(st.a, x->stream));
     if (steady && it == n_iter - 1) HIP_TRY(hipEventRecord(st.b, x->stream));
     if (x->kernel == WDPM_KERNEL_FUSED) {
@@ -916,7 +929,7 @@ int wdpm_iterate(wdpm_ctx *x, int32_t n_iter) {
       x->flush_pending = false;
       x->drain_owed = x->p.module == WDPM_DRAIN;     /* this iteration's drain(): owed to the next launch or reader */
       x->launches += 1;
-      continue;
+      return 0;
     } else {
       for (int oi = 1; oi <= 3; oi++)
         for (int oj = 1; oj <= 3; oj++)
@@ -925,7 +938,65 @@ int wdpm_iterate(wdpm_ctx *x, int32_t n_iter) {
     }
     if (x->p.module == WDPM_DRAIN)
       HIP_TRY(wdpm_launch_drain_outlet(x->d_w[x->cur], x->d_dem, x->g, x->d_scal, x->stream));
+    return 0;
+  };
+  int it = 0;
+  /* Small rasters are launch-bound (482 x 471: 5.2 us of kernel, 6.3 us from launch to launch when the host queues them one by one):
+   * the iterations between a block's first (threshold flush on load) and last (max diff) are replayed as HIP graphs of kGraphIters
+   * launches each, captured from this very loop (round 5; `tools/graph_probe.py` measured +21 % for add at that size, +3 % for drain,
+   * nothing from 2048^2 up).  Only where a launch keeps no state on the host (the relay / triangle kernels: no tile flags, no balance
+   * table) and nobody times the launches; the rasters ping-pong between two buffers within a block, so an even count returns to
+   * the state it was captured in.  WDPM_GRAPH=0: never. */
+  constexpr int kGraphIters = 32;
+  if (x->kernel == WDPM_KERNEL_FUSED && !x->timing && n_iter >= kGraphIters + 2 && x->graph_mode != 0) {
+    if (x->graph_mode < 0) { const char *e = getenv("WDPM_GRAPH"); x->graph_mode = (e && atoi(e) == 0) ? 0 : 1; }
+    const bool balanced = x->bal.mode == 2 || (x->bal.mode == 1 && x->wide_tri_ok);
+    const bool track = x->tiles_mode != 0 && !x->signed_zero_safe && !balanced;
+    const int chunk_rows = x->p.chunk_rows >= 3 ? x->p.chunk_rows : (track && x->sparse ? kSparseChunkRows : 0);
+    TilePlan tq{nullptr, nullptr, 0, 0, nullptr, 0, 0, 0, 0, 0, x->wide_tri_ok ? 1 : 0};
+    if (x->graph_mode == 1 && wdpm_small_rows_take(x->p.module, x->g, chunk_rows, x->signed_zero_safe ? 1 : 0, track ? &tq : nullptr)) {
+      if (one_iteration(it++)) return 1;                   /* the block's first launch: as ever */
+      while (n_iter - 1 - it >= kGraphIters && x->graph_mode == 1) {
+        wdpm_ctx::GraphEntry key{x->cur, x->old, launch_flags(x), x->drain_owed ? 1 : 0, chunk_rows, x->g.dr, x->g.dc, x->wide_tri_ok ? 1 : 0,
+                                 x->code.force, x->code.q, x->code.h, nullptr};
+        hipGraphExec_t exec = nullptr;
+        for (const auto &ge : x->graphs)
+          if (ge.cur == key.cur && ge.old == key.old && ge.flags == key.flags && ge.drain_owed == key.drain_owed && ge.chunk_rows == key.chunk_rows &&
+              ge.dr == key.dr && ge.dc == key.dc && ge.wide == key.wide && ge.force == key.force && ge.q == key.q && ge.h == key.h) { exec = ge.exec; break; }
+        if (!exec) {
+          /* capture kGraphIters launches of this loop (nothing runs yet; the host's bookkeeping moves on as if they had) */
+          hipGraph_t graph = nullptr;
+          if (hipStreamBeginCapture(x->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); x->graph_mode = 0; break; }
+          int bad = 0;
+          for (int k = 0; k < kGraphIters && !bad; k++) bad = one_iteration(it + k);
+          const hipError_t ec = hipStreamEndCapture(x->stream, &graph);
+          if (bad || ec != hipSuccess || !graph || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+            if (graph) (void)hipGraphDestroy(graph);
+            (void)hipGetLastError();
+            x->graph_mode = 0;
+            return fail("wdpm_iterate: capturing %d iterations as a HIP graph failed (set WDPM_GRAPH=0 to launch them one by one)", kGraphIters);
+          }
+          (void)hipGraphDestroy(graph);
+          if (x->graphs.size() >= 12) drop_graphs(x);
+          key.exec = exec;
+          x->graphs.push_back(key);
+          HIP_TRY(hipGraphLaunch(exec, x->stream));
+          x->graph_launches++;
+        } else {
+          HIP_TRY(hipGraphLaunch(exec, x->stream));
+          x->graph_launches++;
+          /* what kGraphIters passes through one_iteration() leave on the host: the same current raster (an even count), nothing known
+           * about dry tiles of the two rasters written, drain() owed by the last launch */
+          x->zero_valid[x->cur] = x->zero_valid[free_slot(x)] = false;
+          x->drain_owed = x->p.module == WDPM_DRAIN;
+          x->launches += kGraphIters;
+        }
+        it += kGraphIters;
+      }
+    }
   }
+  for (; it < n_iter; it++)
+    if (one_iteration(it)) return 1;
   if (x->timing) {
     HIP_TRY(hipEventRecord(ep.b, x->stream));
     x->pending.push_back(ep);

@@ -79,6 +79,17 @@ struct wdpm_ctx {
   bool pending_join;
   hipEvent_t ev_copy[2];        /* wdpm_copy_rows: [0] "my rows are produced" as source, [1] "the copy has read them" as destination */
   /* stencil timing */
+  /* HIP graphs of steady small-raster iterations (wdpm_capi.hip: wdpm_iterate).  A launch of the relay / triangle kernels keeps no state
+   * on the host, and within a block the water rasters ping-pong between two buffers: an even number of iterations captured once from
+   * the context's own launches replays any number of times from the same pair.  What a captured launch was given is the key. */
+  struct GraphEntry {
+    int cur, old, flags, drain_owed, chunk_rows, dr, dc, wide, force;
+    const void *q, *h;
+    hipGraphExec_t exec;
+  };
+  std::vector<GraphEntry> graphs;
+  int graph_mode;               /* -1 unknown, 0 off (WDPM_GRAPH=0, or a capture failed on this context), 1 on */
+  int64_t graph_launches;       /* graphs launched so far (WDPM_OPT_GRAPH_LAUNCHES) */
   std::vector<EventPair> pending;
   std::vector<EventPair> pool;
   /* the same for the launches of a call between its first and its last (those two may be the flush-on-load and the

@@ -1579,7 +1579,7 @@ static hipError_t dpp_selfcheck(hipStream_t s) {
 hipError_t wdpm_launch_small_rows(int module, const double *w_in, double *w_out, const double *dem, const DemCode &code,
                                   const SlabGeom &g, int A0, int out_last, int chunk_rows, int signed_zero_safe, bool flush,
                                   double thres, int drain_owed, double *totaldrain, hipStream_t s, TilePlan *tiles,
-                                  const MaxDiffArgs *md, bool fold_md, bool plain, int no_clamp, bool *taken)
+                                  const MaxDiffArgs *md, bool fold_md, bool plain, int no_clamp, bool *taken, bool dry)
 #if !defined(WDPM_TU) || WDPM_TU == 2
 {
   *taken = false;
@@ -1647,6 +1647,7 @@ hipError_t wdpm_launch_small_rows(int module, const double *w_in, double *w_out,
                             (nwg4 * 4 <= 4 * cus || ((wide || items <= slots_now) && (tall ? r8 : r4) <= (module == 2 ? 10 : 7)) ||
                              env_relay == 2);
       if (env_relay && !fold_md && relay_ok) {
+        if (dry) { *taken = true; return hipSuccess; }      /* (wdpm_small_rows_take: the caller only asks) */
         const dim3 rgrid(((unsigned)nwg + 7) / 8 * 8), rblock(tall ? 512 : 256);
         int relay_plain = (module != 2 && tall && r8 >= 6) ? 1 : 0;   // 2000^2 25.8 -> 25.1 us, 3000^2 50.1 -> 46.1
         // bit 1: stage priorities, where workgroups share SIMDs and the launch is a few rounds long (see the kernel; WDPM_RELAY_PRIO=0/2: never / always)
@@ -1676,6 +1677,7 @@ hipError_t wdpm_launch_small_rows(int module, const double *w_in, double *w_out,
     // the block's last launch (max diff folded in) stays here where three rows per wave do (round 3); six-row waves have no
     // registers left for the snapshot's rows: those launches go to the marching kernel as before
     if (env_tri && !signed_zero_safe && !(fold_md && two) && chunk_rows < 3 && (items <= tri_limit || env_tri == 2)) {
+      if (dry) { *taken = true; return hipSuccess; }
       if (two) {
         nch = (out_last - A0 - 1 + 5) / 6;
         if (nch < 1) nch = 1;
@@ -1707,6 +1709,17 @@ hipError_t wdpm_launch_fused(int module, const double *w_in, double *w_out, cons
                                 drain_owed, totaldrain, s, tiles, md, 0, plain_water, bal);
 }
 
+/* would a whole-slab steady launch (no flush, no folded max diff) of this context go to the relay / triangle kernels of small rasters?
+ * Those launches keep no state on the host between iterations (no tile flags, no balance table), which is what lets the caller
+ * replay a run of them as a HIP graph (wdpm_capi.hip: GraphCache).  Asks the dispatch itself; launches nothing. */
+bool wdpm_small_rows_take(int module, const SlabGeom &g, int chunk_rows, int signed_zero_safe, TilePlan *tiles) {
+  bool taken = false;
+  const DemCode none{nullptr, 0.0, 1.0, 1.0, 0, nullptr, nullptr, 0};
+  if (wdpm_launch_small_rows(module, nullptr, nullptr, nullptr, none, g, 0, g.rows - 1, chunk_rows, signed_zero_safe, false, 0.0, 0, nullptr,
+                             nullptr, tiles, nullptr, false, false, 0, &taken, true) != hipSuccess) return false;
+  return taken;
+}
+
 /* one iteration restricted to the output rows [A0 + 2 (0 when A0 == 0), out_last]; A0 % 3 == 0 */
 hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out, const double *dem,
                                   const DemCode &code, const SlabGeom &g, int A0, int out_last, int chunk_rows,
@@ -1729,7 +1742,7 @@ hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out,
   {
     bool taken = false;
     e = wdpm_launch_small_rows(module, w_in, w_out, dem, code, g, A0, out_last, chunk_rows, signed_zero_safe, flush != nullptr, thres,
-                               drain_owed, totaldrain, s, tiles, md, fold_md, plain, no_clamp, &taken);
+                               drain_owed, totaldrain, s, tiles, md, fold_md, plain, no_clamp, &taken, false);
     if (taken || e != hipSuccess) return e;
   }
   int nstrips = 1;

@@ -160,6 +160,8 @@ hipError_t wdpm_launch_fused(int module, const double *w_in, double *w_out, cons
                              const SlabGeom &g, int chunk_rows, int signed_zero_safe, const double *flush,
                              int drain_owed, double *totaldrain, hipStream_t s, TilePlan *tiles = nullptr,
                              const MaxDiffArgs *md = nullptr, int plain_water = 0, XcdBalance *bal = nullptr);
+/* whether a steady whole-slab launch of this geometry goes to the small-raster kernels (relay / triangle): see wdpm_fused.hip */
+bool wdpm_small_rows_take(int module, const SlabGeom &g, int chunk_rows, int signed_zero_safe, TilePlan *tiles);
 hipError_t wdpm_launch_fused_rows(int module, const double *w_in, double *w_out, const double *dem,
                                   const DemCode &code, const SlabGeom &g, int A0, int out_last, int chunk_rows,
                                   int signed_zero_safe, const double *flush, int drain_owed, double *totaldrain,
